@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's configuration layer (the inputs of the hot path).
+
+Same names and meaning as the reference so that a `Main.m` user finds the same knobs:
+
+* ``SetVehicleParameters(tree)``  -- ABO/Functions/Settings/SetVehicleParameters.m:12-133
+  (``tree='ABO'``: light commercial van; ``tree='ORIG'``: BMW i3 of
+  ORIG/Functions/Settings/SetVehicleParameters.m).
+* ``Settings(OPTsettings, tree)`` -- ABO/Settings.m:1-256 (custom use case 0 only; the canned
+  use cases of GetUseCase.m are out of scope for now).
+* ``GenerateUseCase`` / ``SimplifyPWA`` -- ABO/Functions/Settings/GenerateUseCase.m:50-116,
+  ABO/Functions/PWA_function_manipulation/SimplifyPWA.m:14-49 (including its `doms(j)` quirk).
+* ``Run_DrivingCycle`` -- ABO/Run_DrivingCycle.m:13-47 (lead-vehicle trace from a 10 Hz cycle).
+
+Everything here is plain numpy on the host; it only prepares the plain-old-data config that
+``eepacc_create`` receives.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Any
+
+import numpy as np
+
+__all__ = ["SetVehicleParameters", "Settings", "GenerateUseCase", "SimplifyPWA",
+           "Run_DrivingCycle", "default_opt"]
+
+
+def SetVehicleParameters(tree: str = "ABO") -> Dict[str, float]:
+    V: Dict[str, float] = {}
+    if tree == "ABO":      # ABO/.../SetVehicleParameters.m:12-19 ("DAILY")
+        V.update(m=2620.0, A_f=4.614, c_d=0.46, L=3.52, h_g=1.2, WD_s_F=0.45)
+        V.update(F0=275.0, F1=0.0, F2=1.305072)                       # :32-34
+        V.update(p00=-1.178, p10=0.1154, p01=0.001764)                # :80-82
+        V.update(c_r=0.0107, R_w=0.361)                               # :91-92
+    elif tree == "ORIG":   # ORIG/.../SetVehicleParameters.m (BMW i3)
+        V.update(m=1443.0, A_f=2.38, c_d=0.29, L=2.57, h_g=0.47, WD_s_F=0.53)
+        V.update(F0=0.0, F1=0.0, F2=0.0, p00=0.0, p10=0.0, p01=0.0)
+        V.update(c_r=0.0064, R_w=0.3498)
+    else:
+        raise ValueError("tree must be 'ABO' or 'ORIG'")
+    V["L_f"] = V["WD_s_F"] * V["L"]
+    V["L_r"] = V["L"] - V["L_f"]
+    V["P_m_max"] = 125 * 1e3
+    V["T_m_max"] = 250.0
+    V["omega_m_r"] = 4800 / 60 * 2 * math.pi
+    V["omega_m_max"] = 11400 / 60 * 2 * math.pi
+    V["beta_gb"] = 9.665
+    V["beta_fd"] = 1.0
+    V["phi"] = V["beta_gb"] * V["beta_fd"] / V["R_w"]
+    V["v_max"] = 150 / 3.6
+    V["eta_gb"] = 0.985
+    V["eta_fd"] = 0.93
+    V["eta_TF"] = V["eta_gb"] * V["eta_fd"]
+    V["lambda"] = 1.05
+    V["mu"] = 0.8
+    V["rho_a"] = 1.225
+    V["g"] = 9.81
+    V["zeta_a"] = .5 * V["c_d"] * V["rho_a"] * V["A_f"]
+    return V
+
+
+def SimplifyPWA(doms, vals):
+    """ABO/Functions/PWA_function_manipulation/SimplifyPWA.m:14-49 (1-based loops restated)."""
+    doms = [float(x) for x in doms]
+    vals = [float(x) for x in vals]
+    n = len(doms)
+    doms_, vals_ = [doms[0]], [vals[0]]
+    for i in range(1, n - 1):                                   # MATLAB i = 2:length-1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prevSlope = np.float64(vals[i] - vals[i - 1]) / np.float64(doms[i] - doms[i - 1])
+            currSlope = np.float64(vals[i + 1] - vals[i]) / np.float64(doms[i + 1] - doms[i])
+        if prevSlope != currSlope:
+            doms_.append(doms[i])
+            vals_.append(vals[i])
+    doms2 = doms_ + [doms[-1]]
+    vals2 = vals_ + [vals[-1]]
+    domsNew, valsNew = [], []
+    j = 0                                                        # MATLAB j = 1
+    for i in range(len(doms2) - 1):
+        if doms2[i] == doms2[i + 1]:
+            if vals2[i] == vals2[i + 1]:
+                pass
+            else:
+                domsNew.append(doms2[i] - .1)
+                valsNew.append(vals2[i])
+                j += 1
+        else:
+            domsNew.append(doms2[j])                            # sic: doms(j), :43-44
+            valsNew.append(vals2[j])
+            j += 1
+    domsNew.append(doms2[-1])
+    valsNew.append(vals2[-1])
+    return np.array(domsNew), np.array(valsNew)
+
+
+def GenerateUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
+    """ABO/Functions/Settings/GenerateUseCase.m:50-116."""
+    def _empty(key):
+        return key not in OPT or OPT[key] is None or np.size(OPT[key]) == 0
+    if _empty("speedLimZones"):
+        OPT["speedLimZones"] = np.array([[1e5, 0.0], [1e5, 1.0]])
+    if _empty("curves"):
+        OPT["curves"] = np.array([[1 / 1e5, 1.0, 2.0]])
+    if _empty("slopes"):
+        OPT["slopes"] = np.array([[0.0, 1.0, 2.0]])
+    sRes = OPT["sRes"]
+    Z = np.atleast_2d(np.asarray(OPT["speedLimZones"], dtype=np.float64))
+    curves = np.atleast_2d(np.asarray(OPT["curves"], dtype=np.float64))
+    slopes = np.atleast_2d(np.asarray(OPT["slopes"], dtype=np.float64))
+    # maximum speed :53-71
+    n = Z.shape[0]
+    Z = Z[np.argsort(Z[:, 1], kind="stable")]
+    Z = Z * np.array([1 / 3.6, 1.0])
+    Z = np.vstack([Z, [Z[-1, 0], 1e5]])
+    v_sl = np.zeros(2 * n + 1)
+    s_sl = np.zeros(2 * n + 1)
+    s_sl[0] = -1
+    v_sl[0] = Z[0, 0]
+    for i in range(1, 2 * n, 2):                                 # MATLAB i = 1:2:2n
+        q = (i + 1) // 2                                         # 1-based zone index
+        s_sl[i] = Z[q - 1, 1]
+        v_sl[i] = Z[q - 1, 0]
+        s_sl[i + 1] = Z[q, 1] - 1
+        v_sl[i + 1] = Z[q - 1, 0]
+    s_sl, v_sl = SimplifyPWA(s_sl, v_sl)
+    # curvature :75-93
+    curvature = np.zeros(int(np.max(curves[:, 2])))
+    for i in range(curves.shape[0]):
+        curvature[int(curves[i, 1]) - 1:int(curves[i, 2])] = abs(curves[i, 0])
+    curvature[np.abs(curvature) <= 1e-6] = 1e-6
+    s_curv = np.arange(1, len(curvature) + 1, sRes, dtype=np.float64)
+    s_curv, curvature = SimplifyPWA(s_curv, curvature)
+    s_curv = np.concatenate([s_curv, [s_curv[-1] + 1, s_curv[-1] + 2]])
+    curvature = np.concatenate([curvature, [1e-6, 1e-6]])
+    # slope :97-108
+    slope = np.zeros(int(np.max(slopes[:, 2])))
+    for i in range(slopes.shape[0]):
+        slope[int(slopes[i, 1]) - 1:int(slopes[i, 2])] = slopes[i, 0]
+    slope = np.arctan(slope / 100)
+    s_slope = np.arange(1, len(slope) + 1, sRes, dtype=np.float64)
+    s_slope, slope = SimplifyPWA(s_slope, slope)
+    OPT.update(s_speedLim=s_sl, v_speedLim=v_sl, s_curv=s_curv, curvature=curvature,
+               s_slope=s_slope, slope=slope)
+    return OPT
+
+
+def default_opt() -> Dict[str, Any]:
+    """The script-level settings of ABO/Main.m:22-53."""
+    return dict(createGifs=False, IncludeTV=True, useCaseNum=0, Ts=0.5, t_sim=435.0)
+
+
+def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 20) -> Dict[str, Any]:
+    """ABO/Settings.m:1-256.  ``N_hor`` replaces the literal ``ones(1,20)`` of :101
+    (BASELINE's N=30/60 configs change exactly that line)."""
+    OPT = dict(default_opt() if OPT is None else OPT)
+    OPT["tree"] = tree
+    # NLP / FB weights :12-46
+    W = [220.0, 0.3 * 3e5, 0.3 * 1e7, 4e5, 8e3, 1e7 * 9e0, 1e7]
+    OPT["W_NLP"] = np.array(W)
+    W = [50.0, 0.3 * 3e5, 0.3 * 1e7, 4e5, 8e3, 1e7 * 9e0, 1e7]
+    OPT["W_FB"] = np.array(W)
+    if tree == "ABO":      # :48-64 (7 weights, first = w_FC)
+        OPT["W_AB"] = 1 * np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0])
+    else:                  # ORIG/Settings.m:48-62 (6 weights)
+        w_c, w_v, w_h, w_f = 0.1, 8e5, 1e4, 1e10
+        OPT["W_AB"] = 1e-3 * np.array([w_c * 3e5, w_c * 1e7, w_v, w_h, w_f * 9e0, w_f])
+    Ts = OPT["Ts"]
+    OPT.update(s_init=0.0, v_init=0 / 3.6, a_minus1=0.0)                     # :85-87
+    OPT["FBuseTaylor"] = True                                                # :98
+    moveBlockingSettings = np.ones(N_hor, dtype=int)                         # :101
+    OPT["N_hor"] = int(moveBlockingSettings.sum())
+    OPT.update(paramEstSetting=1, TVestSetting=1, tConstACC_ego=3.0, tConstACC_tar=5.0)  # :105-108
+    OPT["N_integratePlant"] = 10                                             # :111
+    OPT["solverToUse"] = 1                                                   # :114
+    OPT["Tvec"] = Ts * np.ones(OPT["N_hor"])                                 # :122
+    OPT["s_goal"] = math.inf                                                 # :143
+    OPT.update(sRes=1, tRes=1)
+    if OPT["useCaseNum"] == 0:                                               # :150-193
+        OPT.setdefault("slopes", np.zeros((0, 3)))
+        OPT.setdefault("speedLimZones", np.array([[60.0, 0.0], [50.0, 1000.0]]))
+        OPT.setdefault("curves", np.zeros((0, 3)))
+        OPT.setdefault("stopLoc", np.zeros(0))
+        OPT.setdefault("TLLoc", np.zeros((0, 4)))
+        OPT.setdefault("cutOffDist", 3.5e3)
+    else:
+        raise NotImplementedError("GetUseCase.m canned use cases are out of scope (SURVEY 8f)")
+    OPT.update(h_min=2.0, tau_min=0.5)                                       # :203-204
+    OPT.update(TVlength=4.0, TVinitDist=10.0, TVinitVel=0.0, TV_N_hor=20, TV_Ts=0.5)  # :207-212
+    OPT.update(stopVel=0.2, stopRefDist=100.0, stopRefVelSlope=1.0, TLStopRegionSize=2.0,
+               TLstopVel=-1.0, alpha_TTL=3.34)                               # :221-226
+    OPT["b_quadr"] = np.array([185, 1.296e-20, 2.301, 0, 0.003728, -0.000181])  # :229
+    OPT["b_fifthOrder"] = np.array([
+        185, 0.427461350854152, 1.33881428409239, 0,
+        0.00357911242725773, -0.000183195720362408, 0,
+        2.41017657319644e-07, 1.92524236475911e-07,
+        -1.21266753753542e-08, 2.69420315493954e-12,
+        -6.73422331977247e-11, -4.65716485427471e-11,
+        -3.29148609115376e-11, 8.05602619603684e-12,
+        4.07099563902699e-16, 5.70507905296593e-15,
+        4.78644673413403e-15, 2.49448524129528e-15,
+        1.49184094719691e-15, -5.76405750523528e-16])                        # :230-238
+    Mb = np.zeros(OPT["N_hor"], dtype=np.int32)                              # :243-250
+    j = 0
+    for n in moveBlockingSettings:
+        Mb[j:j + n] = [0] + [1] * (n - 1)
+        j += n
+    OPT["Mb"] = Mb
+    OPT["stopRefvelIncr"] = OPT["stopRefDist"] * OPT["stopRefVelSlope"]
+    return GenerateUseCase(OPT)
+
+
+def Run_DrivingCycle(OPT: Dict[str, Any], V_TO_10Hz: np.ndarray | None = None,
+                     V_TO_resampled: np.ndarray | None = None):
+    """ABO/Run_DrivingCycle.m:13-47.  Pass either the raw 10 Hz speed trace (resampled here
+    like `resample(V_TO,1,5)`) or an already resampled one."""
+    if V_TO_resampled is None:
+        from scipy.signal import resample_poly
+        V_TO = resample_poly(np.asarray(V_TO_10Hz, dtype=np.float64), 1, 5)   # :16
+    else:
+        V_TO = np.array(V_TO_resampled, dtype=np.float64)
+    V_TO = np.where(V_TO < 0.1, 0.0, V_TO)                                   # :17
+    Ts = OPT["TV_Ts"]
+    n_cycle = int(round(OPT["t_sim"] / Ts))
+    v = np.zeros(n_cycle + 1)
+    s = np.zeros(n_cycle + 1)
+    s[0] = OPT["TVinitDist"]
+    for i in range(1, n_cycle):                                              # MATLAB i = 2:n_cycle
+        v[i] = V_TO[i]
+        s[i] = s[i - 1] + Ts * V_TO[i]
+    v[n_cycle] = v[n_cycle - 1]                                              # :45-46
+    s[n_cycle] = s[n_cycle - 1]
+    return s, v

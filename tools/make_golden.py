@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Extract golden vectors from the reference's saved-solution .mat files.
+
+Run in the build container only (needs /root/reference, which never travels to the
+GPU box).  Output: small compressed .npz fixtures under tests/golden/ holding *data only*
+(trajectories, final-step dense H/G, timing vectors, the lead-vehicle speed trace).
+
+Sources (reference file -> what it pins), see SURVEY.md section 4:
+  ABO/saved{ABMPCsol,FBMPCsol}.mat, ORIG/saved{ABMPCsol,FBMPCsol}.mat
+      written by ABO/Main.m:98,107,116,125 from the optSol struct of
+      ABO/RunOpt_ABMPC.m:354-404 / ABO/RunOpt_FBMPC.m:343-397.
+  ABO/DrivingCycles/TO01_EAD.mat: V_TO -> lead trace of ABO/Run_DrivingCycle.m:13-47.
+
+The .mat files are MATLAB v5 containers read with scipy.io.loadmat (no code execution).
+The 1:5 resampling of V_TO uses scipy.signal.resample_poly, which reproduces MATLAB's
+`resample(V_TO,1,5)` (Kaiser beta=5 windowed sinc, 2*10*5+1 taps) -- SURVEY.md section 4
+records 4.5e-13 agreement with the golden xi_h rows.
+"""
+import os
+import sys
+import numpy as np
+import scipy.io as sio
+from scipy.signal import resample_poly
+
+REF = "/root/reference"
+ABO = os.path.join(REF, "ACCMPC-ABO_CasADi")
+ORIG = os.path.join(REF, "MATLAB_CasADi")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+VEC_FIELDS = ["s_opt", "v_opt", "Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt",
+              "xi_f_opt", "P_opt", "E_opt", "a_opt", "j_opt", "Tm_opt", "rpm_opt",
+              "DistHor", "exitMessage", "tLoop", "tSolve", "solverTime",
+              "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f", "cost_P"]
+
+
+def extract(path, var, out_name):
+    m = sio.loadmat(path, squeeze_me=True, struct_as_record=False)
+    sol = m[var]
+    d = {}
+    for f in VEC_FIELDS:
+        if hasattr(sol, f):
+            d[f] = np.asarray(getattr(sol, f), dtype=np.float64).ravel()
+    d["H"] = np.asarray(sol.H, dtype=np.float64)
+    d["G"] = np.asarray(sol.G, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, out_name), **d)
+    print(out_name, {k: v.shape for k, v in d.items() if k in ("s_opt", "H", "G")})
+
+
+def lead_trace():
+    m = sio.loadmat(os.path.join(ABO, "DrivingCycles", "TO01_EAD.mat"), squeeze_me=True)
+    V_TO = np.asarray(m["V_TO"], dtype=np.float64).ravel()
+    V2 = resample_poly(V_TO, 1, 5)          # Run_DrivingCycle.m:16
+    np.savez_compressed(os.path.join(OUT, "lead_TO01_EAD.npz"), V_TO_10Hz=V_TO, V_TO_2Hz=V2)
+    print("lead_TO01_EAD.npz", V_TO.shape, V2.shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    extract(os.path.join(ABO, "savedABMPCsol.mat"), "ABMPCsol", "abo_abmpc.npz")
+    extract(os.path.join(ABO, "savedFBMPCsol.mat"), "FBMPCsol", "abo_fbmpc.npz")
+    extract(os.path.join(ORIG, "savedABMPCsol.mat"), "ABMPCsol", "orig_abmpc.npz")
+    extract(os.path.join(ORIG, "savedFBMPCsol.mat"), "FBMPCsol", "orig_fbmpc.npz")
+    lead_trace()
+
+
+if __name__ == "__main__":
+    sys.exit(main())
