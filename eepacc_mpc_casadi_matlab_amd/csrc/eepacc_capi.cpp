@@ -1,0 +1,286 @@
+// eepacc_capi.cpp -- C-ABI of libeepacc (include/eepacc.h): handle management, validation of the
+// reference settings, one-time host precomputation, kernel launches.  Compiled with hipcc.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "eepacc_device.h"
+#include "../../include/eepacc.h"
+
+namespace eepacc {
+size_t ab_smem_bytes(int N);
+hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const double* v, const double* a_prev,
+                          const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                          unsigned long long* codes, double* out, double* s_pred, double* v_pred,
+                          int32_t* status, int32_t* iters, hipStream_t stream);
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int n_steps, const double* s0, const double* v0,
+                            const double* a_m1, const double* s_tv, const double* v_tv, double* traj,
+                            int32_t* status, int32_t* iters_total, hipStream_t stream);
+hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
+                              double* P, double* E, hipStream_t stream);
+hipError_t set_max_smem();
+}  // namespace eepacc
+
+using eepacc::DevCfg;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(EEPACC_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct eepacc_handle {
+    int device = 0;
+    int max_batch = 0;
+    DevCfg cfg;
+    DevCfg* d_cfg = nullptr;
+    double* d_Hinv = nullptr;
+    unsigned long long* d_codes = nullptr;   // [max_batch][64]
+    int32_t* d_iters = nullptr;              // [max_batch]
+    int last_B = 0;
+};
+
+extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
+extern "C" int eepacc_version(void) { return EEPACC_VERSION; }
+
+// symmetric positive definite inverse (Gauss-Jordan in long double; N <= 63)
+static bool spd_inverse(std::vector<long double>& A, int n) {
+    std::vector<long double> I((size_t)n * n, 0.0L);
+    for (int i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0L;
+    for (int k = 0; k < n; ++k) {
+        long double d = A[(size_t)k * n + k];
+        if (!(d > 0.0L)) return false;
+        for (int j = 0; j < n; ++j) { A[(size_t)k * n + j] /= d; I[(size_t)k * n + j] /= d; }
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            long double f = A[(size_t)i * n + k];
+            if (f == 0.0L) continue;
+            for (int j = 0; j < n; ++j) { A[(size_t)i * n + j] -= f * A[(size_t)k * n + j]; I[(size_t)i * n + j] -= f * I[(size_t)k * n + j]; }
+        }
+    }
+    A.swap(I);
+    return true;
+}
+
+static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& C, std::vector<double>& Hinv) {
+    memset(&C, 0, sizeof(C));
+    const int N = S->N_hor;
+    if (N < 2 || N > eepacc::kMaxN) return fail(EEPACC_EINVAL, "N_hor must be in [2, 63]");
+    if (!S->Tvec) return fail(EEPACC_EINVAL, "Tvec is NULL");
+    if (S->solverToUse != 1) return fail(EEPACC_ENOTSUP, "only solverToUse == 1 (dense QP, ABO/Settings.m:114) is built");
+    if (S->paramEstSetting != 0 && S->paramEstSetting != 1) return fail(EEPACC_ENOTSUP, "paramEstSetting 2 is not built yet");
+    if (S->TVestSetting != 0 && S->TVestSetting != 1) return fail(EEPACC_EINVAL, "TVestSetting must be 0 or 1");
+    if (S->n_speedLim < 1 || S->n_speedLim > eepacc::kMaxKnots || S->n_curv < 1 || S->n_curv > eepacc::kMaxKnots ||
+        S->n_slope < 1 || S->n_slope > eepacc::kMaxKnots || S->n_stop < 0 || S->n_stop > eepacc::kMaxStops ||
+        S->n_TL < 0 || S->n_TL > eepacc::kMaxTL)
+        return fail(EEPACC_EINVAL, "route table sizes out of range");
+    if (S->N_integratePlant < 1) return fail(EEPACC_EINVAL, "N_integratePlant < 1");
+    C.N = N;
+    C.ab_fuel_term = S->ab_fuel_term; C.ab_route_rows = S->ab_route_rows;
+    C.paramEstSetting = S->paramEstSetting; C.TVestSetting = S->TVestSetting;
+    C.N_integratePlant = S->N_integratePlant;
+    C.max_iter = 60 * N + 200;
+    C.const_T = 1;
+    C.tau[0] = 0.0;
+    for (int k = 0; k < N; ++k) {
+        if (!(S->Tvec[k] > 0.0)) return fail(EEPACC_EINVAL, "Tvec entries must be positive");
+        C.Tvec[k] = S->Tvec[k];
+        C.tau[k + 1] = C.tau[k] + S->Tvec[k];
+        if (S->Tvec[k] != S->Tvec[0]) C.const_T = 0;
+        if (S->Mb && S->Mb[k] != 0) C.mb_any = 1;
+    }
+    if (C.mb_any) return fail(EEPACC_ENOTSUP, "move blocking (Mb != 0, ABO/Settings.m:243-250) is not built yet");
+    C.w_FC = S->ab_fuel_term ? S->W_AB[0] : 0.0;
+    C.w_a = S->W_AB[1]; C.w_j = S->W_AB[2]; C.w_v = S->W_AB[3]; C.w_h = S->W_AB[4]; C.w_s = S->W_AB[5]; C.w_f = S->W_AB[6];
+    if (!(C.w_a > 0.0) || !(C.w_h > 0.0) || C.w_v < 0 || C.w_s < 0 || C.w_f < 0 || C.w_j < 0)
+        return fail(EEPACC_EINVAL, "W_AB weights must be positive (w_a, w_h) / non-negative");
+    C.tau_min = S->tau_min; C.h_min = S->h_min; C.s_goal = S->s_goal;
+    C.tConstACC_ego = S->tConstACC_ego; C.tConstACC_tar = S->tConstACC_tar;
+    C.m = V->m; C.lambda = V->lambda; C.g = V->g; C.zeta_a = V->zeta_a; C.c_r = V->c_r; C.mu = V->mu; C.L = V->L;
+    C.L_f = V->L_f; C.h_g = V->h_g; C.phi = V->phi; C.T_m_max = V->T_m_max; C.P_m_max = V->P_m_max;
+    C.eta_TF = V->eta_TF; C.omega_m_r = V->omega_m_r; C.v_max = V->v_max;
+    C.p01 = V->p01; C.p10 = V->p10; C.F2 = V->F2;
+    C.cq = C.w_FC * V->p01 * V->F2;
+    C.glin_v = C.w_FC * V->p10;
+    C.glin_a = C.w_FC * V->p01 * V->lambda * V->m;
+    C.n_speedLim = S->n_speedLim; C.n_curv = S->n_curv; C.n_slope = S->n_slope; C.n_stop = S->n_stop; C.n_TL = S->n_TL;
+    for (int i = 0; i < S->n_speedLim; ++i) { C.s_speedLim[i] = S->s_speedLim[i]; C.v_speedLim[i] = S->v_speedLim[i]; }
+    const double alpha = S->alpha_TTL;
+    for (int i = 0; i < S->n_curv; ++i) {
+        C.s_curv[i] = S->s_curv[i];
+        C.vcurv_tab[i] = alpha * pow(fabs(S->curvature[i]), -1.0 / 3.0);   // EstimateRouteAndComfortBounds.m:106,108
+    }
+    C.const_slope = 1;
+    for (int i = 0; i < S->n_slope; ++i) {
+        C.s_slope[i] = S->s_slope[i]; C.slope[i] = S->slope[i];
+        if (S->slope[i] != S->slope[0]) C.const_slope = 0;
+    }
+    C.theta0 = S->slope[0]; C.sin_theta0 = sin(C.theta0); C.cos_theta0 = cos(C.theta0);
+    for (int i = 0; i < S->n_stop; ++i) C.stopLoc[i] = S->stopLoc[i];
+    for (int i = 0; i < 4 * S->n_TL; ++i) C.TLLoc[i] = S->TLLoc[i];
+    C.stopRefDist = S->stopRefDist; C.stopRefVelSlope = S->stopRefVelSlope; C.stopVel = S->stopVel;
+    C.TLstopVel = S->TLstopVel; C.TLStopRegionSize = S->TLStopRegionSize;
+    for (int i = 0; i < 21; ++i) C.b5[i] = S->b_fifthOrder[i];
+    // a-space Hessian of the condensed objective (step invariant for AB):
+    //   H = 2 cq Sv'Sv + 2 w_a I + jerk tridiagonal (CreateQP_AB.m:162-180 through Psi)
+    std::vector<long double> H((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            // sum over stages k = max(i,j)+1 .. N-1 of T_i T_j
+            int cnt = N - 1 - (i > j ? i : j);
+            if (cnt > 0) H[(size_t)i * N + j] += 2.0L * C.cq * C.Tvec[i] * C.Tvec[j] * cnt;
+        }
+    for (int k = 0; k < N; ++k) {
+        H[(size_t)k * N + k] += 2.0L * C.w_a;
+        long double qj = 2.0L * C.w_j / ((long double)C.Tvec[k] * C.Tvec[k]);
+        H[(size_t)k * N + k] += qj;
+        if (k > 0) {
+            H[(size_t)(k - 1) * N + (k - 1)] += qj;
+            H[(size_t)k * N + (k - 1)] -= qj;
+            H[(size_t)(k - 1) * N + k] -= qj;
+        }
+    }
+    if (!spd_inverse(H, N)) return fail(EEPACC_EINVAL, "condensed Hessian is not positive definite");
+    Hinv.resize((size_t)N * N);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j)
+            Hinv[(size_t)i * N + j] = (double)(0.5L * (H[(size_t)i * N + j] + H[(size_t)j * N + i]));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, const eepacc_vehicle* V,
+                             int device, int max_batch) {
+    if (!out || !S || !V || max_batch < 1) return fail(EEPACC_EINVAL, "eepacc_create: bad arguments");
+    *out = nullptr;
+    DevCfg C;
+    std::vector<double> Hinv;
+    int rc = build_cfg(S, V, C, Hinv);
+    if (rc != EEPACC_OK) return rc;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(EEPACC_EDEVICE, "no HIP device: libeepacc has no CPU path");
+    if (device < 0 || device >= ndev) return fail(EEPACC_EINVAL, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    eepacc_handle* h = new eepacc_handle();
+    h->device = device; h->max_batch = max_batch;
+    HIPCHK(hipMalloc(&h->d_Hinv, Hinv.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_Hinv, Hinv.data(), Hinv.size() * sizeof(double), hipMemcpyHostToDevice));
+    C.Hinv = h->d_Hinv;
+    h->cfg = C;
+    HIPCHK(hipMalloc(&h->d_cfg, sizeof(DevCfg)));
+    HIPCHK(hipMemcpy(h->d_cfg, &C, sizeof(DevCfg), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_codes, (size_t)max_batch * 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_codes, 0, (size_t)max_batch * 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&h->d_iters, (size_t)max_batch * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->d_iters, 0, (size_t)max_batch * sizeof(int32_t)));
+    HIPCHK(eepacc::set_max_smem());
+    *out = h;
+    return EEPACC_OK;
+}
+
+extern "C" void eepacc_destroy(eepacc_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_cfg) (void)hipFree(h->d_cfg);
+    if (h->d_Hinv) (void)hipFree(h->d_Hinv);
+    if (h->d_codes) (void)hipFree(h->d_codes);
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    delete h;
+}
+
+extern "C" int eepacc_reset(eepacc_handle* h) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemset(h->d_codes, 0, (size_t)h->max_batch * 64 * sizeof(unsigned long long)));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_ab_step(eepacc_handle* h, int B, const double* s, const double* v, const double* a_prev,
+                              const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                              double* out, double* s_pred, double* v_pred, int32_t* status, void* stream) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 0 || B > h->max_batch) return fail(EEPACC_EINVAL, "B exceeds max_batch of the handle");
+    if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out || !status)
+        return fail(EEPACC_EINVAL, "eepacc_ab_step: NULL buffer");
+    if (B == 0) return EEPACC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    h->last_B = B;
+    HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
+                                  s_pred, v_pred, status, h->d_iters, (hipStream_t)stream));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                const double* a_minus1, const double* s_tv, const double* v_tv, double* traj,
+                                int32_t* status, void* stream) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 0 || B > h->max_batch || n_steps < 0) return fail(EEPACC_EINVAL, "bad B / n_steps");
+    if (!s0 || !v0 || !a_minus1 || !s_tv || !v_tv || !traj || !status)
+        return fail(EEPACC_EINVAL, "eepacc_run_abmpc: NULL buffer");
+    if (B == 0 || n_steps == 0) return EEPACC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    h->last_B = B;
+    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status,
+                                    h->d_iters, (hipStream_t)stream));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                     const double* a_minus1, const double* s_tv, const double* v_tv,
+                                     double* traj, int32_t* status) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 1 || B > h->max_batch || n_steps < 1) return fail(EEPACC_EINVAL, "bad B / n_steps");
+    HIPCHK(hipSetDevice(h->device));
+    double *d_in = nullptr, *d_tv = nullptr, *d_traj = nullptr;
+    int32_t* d_status = nullptr;
+    const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
+    HIPCHK(hipMalloc(&d_in, 3 * nB * sizeof(double)));
+    HIPCHK(hipMalloc(&d_tv, 2 * nT * sizeof(double)));
+    HIPCHK(hipMalloc(&d_traj, nT * EEPACC_OUT_N * sizeof(double)));
+    HIPCHK(hipMalloc(&d_status, nT * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(d_in, s0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_in + nB, v0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    int rc = eepacc_run_abmpc(h, B, n_steps, d_in, d_in + nB, d_in + 2 * nB, d_tv, d_tv + nT, d_traj, d_status, nullptr);
+    if (rc == EEPACC_OK) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(traj, d_traj, nT * EEPACC_OUT_N * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(status, d_status, nT * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_in); (void)hipFree(d_tv); (void)hipFree(d_traj); (void)hipFree(d_status);
+    return rc;
+}
+
+extern "C" int eepacc_postprocess(eepacc_handle* h, int B, int n_steps, const double* traj, double* rpm,
+                                  double* Tm, double* P, double* E, void* stream) {
+    if (!h || !traj || !rpm || !Tm || !P || !E) return fail(EEPACC_EINVAL, "eepacc_postprocess: NULL argument");
+    if (B < 1 || n_steps < 1) return EEPACC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(eepacc::launch_postprocess(h->d_cfg, B, n_steps, traj, rpm, Tm, P, E, (hipStream_t)stream));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_last_iterations(eepacc_handle* h, int B, int32_t* iters_host) {
+    if (!h || !iters_host || B < 0 || B > h->max_batch) return fail(EEPACC_EINVAL, "eepacc_last_iterations: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(iters_host, h->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return EEPACC_OK;
+}
+
+// FBMPC (ABO/RunOpt_FBMPC.m) -- declared in the ABI, HIP kernels not built in this round.
+extern "C" int eepacc_fb_step(eepacc_handle*, int, const double*, const double*, const double*, const double*,
+                              const double*, const double*, const double*, const double*, const double*,
+                              const double*, double*, double*, double*, int32_t*, void*) {
+    return fail(EEPACC_ENOTSUP, "eepacc_fb_step: FBMPC kernels are not built yet");
+}
+extern "C" int eepacc_run_fbmpc(eepacc_handle*, int, int, const double*, const double*, const double*,
+                                const double*, const double*, double*, int32_t*, void*) {
+    return fail(EEPACC_ENOTSUP, "eepacc_run_fbmpc: FBMPC kernels are not built yet");
+}
+extern "C" int eepacc_run_fbmpc_host(eepacc_handle*, int, int, const double*, const double*, const double*,
+                                     const double*, const double*, double*, int32_t*) {
+    return fail(EEPACC_ENOTSUP, "eepacc_run_fbmpc_host: FBMPC kernels are not built yet");
+}

@@ -1,0 +1,60 @@
+// eepacc_device.h -- device-side configuration shared by the HIP kernels and the host C-ABI.
+#pragma once
+#include <stdint.h>
+
+namespace eepacc {
+
+constexpr int kWave = 64;
+constexpr int kMaxKnots = 32;     // route table knots kept in the device config
+constexpr int kMaxStops = 16;
+constexpr int kMaxTL = 8;
+constexpr int kMaxN = 63;         // stage k lives on lane k, terminal stage on lane N
+
+// Row types of one stage of the ABMPC QP.  Order/meaning follow the reference row list
+// ABO/Functions/MPCs/CreateQP_AB.m:256-371 (+ the four ORIG rows :307-329); every row is
+//    al*s_k + be*v_k + ga*a_k + de*a_{k-1} - xi_group <= b
+enum RowType : int {
+    R_SLO = 0, R_SHI, R_VLO, R_VHI,                 // hard state bounds  (:256-263)
+    R_AMAX, R_AMIN, R_JMAX, R_JMIN, R_VLIM, R_VCURV, // group F (xi_f)     (:292-322, ORIG :307-317)
+    R_SAFE1, R_SAFE2, R_VSTOP, R_VTL,                // group S (xi_s)     (:355-362, ORIG :319-329)
+    R_VINC,                                          // group V (xi_v)     (:349-352)
+    R_HWP,                                           // group H (xi_h)     (:365-371), quadratic slack
+    kNumRowTypes = 16
+};
+enum Group : int { G_NONE = 0, G_F = 1, G_S = 2, G_V = 3, G_H = 4 };
+
+struct DevCfg {
+    int32_t N;
+    int32_t ab_fuel_term, ab_route_rows;
+    int32_t paramEstSetting, TVestSetting;
+    int32_t N_integratePlant;
+    int32_t const_T;              // 1: all Tvec equal
+    int32_t const_slope;          // 1: slope table is constant -> theta fixed
+    int32_t mb_any;               // move blocking requested (unsupported by the kernels)
+    int32_t max_iter;
+    double Tvec[kMaxN + 1];
+    double tau[kMaxN + 2];        // tau[k] = sum_{i<k} Tvec[i]
+    double w_FC, w_a, w_j, w_v, w_h, w_s, w_f;
+    double tau_min, h_min, s_goal;
+    double tConstACC_ego, tConstACC_tar;
+    // vehicle
+    double m, lambda, g, zeta_a, c_r, mu, L, L_f, h_g, phi, T_m_max, P_m_max, eta_TF, omega_m_r, v_max;
+    double p01, p10, F2;
+    double sin_theta0, cos_theta0, theta0;
+    // objective constants (ABO/.../CreateQP_AB.m:162-187)
+    double cq;                    // w_FC*p01*F2
+    double glin_v;                // w_FC*p10
+    double glin_a;                // w_FC*p01*lambda*m
+    // route tables (GenerateUseCase.m) -- ascending knots
+    int32_t n_speedLim, n_curv, n_slope, n_stop, n_TL;
+    double s_speedLim[kMaxKnots], v_speedLim[kMaxKnots];
+    double s_curv[kMaxKnots], vcurv_tab[kMaxKnots];      // alpha_TTL*|curvature|^(-1/3)
+    double s_slope[kMaxKnots], slope[kMaxKnots];
+    double stopLoc[kMaxStops];
+    double TLLoc[kMaxTL * 4];
+    double stopRefDist, stopRefVelSlope, stopVel, TLstopVel, TLStopRegionSize;
+    double b5[21];                // fifth-order power surface
+    const double* Hinv;           // device, [N][N] row-major, inverse of the a-space Hessian
+};
+
+}  // namespace eepacc

@@ -1,0 +1,1172 @@
+// eepacc_kernels.hip -- hand-written HIP (gfx950) kernels of the batched ABMPC step.
+//
+// One QP instance per 64-lane wavefront: horizon stage k lives on lane k (terminal stage on
+// lane N), the small inverse-KKT block of the working set and all per-stage vectors are staged
+// in LDS.  The horizon condensing is never materialised: every constraint row of the reference
+// QP (ABO/Functions/MPCs/CreateQP_AB.m:256-387) is  al*s_k + be*v_k + ga*a_k + de*a_{k-1} - xi <= b
+// and the condensed double integrator (ABO/RunOpt_ABMPC.m:74-82 +
+// ABO/Functions/MPCs/TransformToDenseFormulation.m:46-68) turns into wave-level prefix /
+// suffix scans.  The slack columns are eliminated exactly (capped-multiplier groups, compliant
+// row for the quadratic slack); the dense active-set solve is a dual (Goldfarb-Idnani type)
+// method on the N x N acceleration block.  DESIGN.md has the derivation.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "eepacc_device.h"
+#include "../../include/eepacc.h"
+
+namespace eepacc {
+
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+constexpr double kInf = 1e300;
+constexpr double kTolViol = 1e-9;
+constexpr double kTolDual = 1e-12;
+
+// ----------------------------------------------------------------------------------------------
+// wave primitives
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ int bcasti(int x, int src) { return __shfl(x, src, 64); }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+// exclusive prefix sum over lanes
+__device__ __forceinline__ double scan_excl(double x) {
+    const int l = lane_id();
+    double y = __shfl_up(x, 1, 64);
+    if (l == 0) y = 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(y, o, 64);
+        if (l >= o) y += t;
+    }
+    return y;
+}
+// exclusive suffix sum over lanes (sum over lanes > me)
+__device__ __forceinline__ double suffix_excl(double x) {
+    const int l = lane_id();
+    double y = __shfl_down(x, 1, 64);
+    if (l == 63) y = 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_down(y, o, 64);
+        if (l + o < 64) y += t;
+    }
+    return y;
+}
+// arg-min / arg-max with integer payload (ties: smallest payload, deterministic)
+__device__ __forceinline__ void wave_argmin(double& v, int& p) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o, 64);
+        int op = __shfl_xor(p, o, 64);
+        if (ov < v || (ov == v && op < p)) { v = ov; p = op; }
+    }
+}
+__device__ __forceinline__ void wave_argmax(double& v, int& p) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o, 64);
+        int op = __shfl_xor(p, o, 64);
+        if (ov > v || (ov == v && op < p)) { v = ov; p = op; }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// row catalogue
+__device__ __forceinline__ int group_of(int t) {
+    return t < R_AMAX ? G_NONE : (t < R_SAFE1 ? G_F : (t < R_VINC ? G_S : (t == R_VINC ? G_V : G_H)));
+}
+__device__ __forceinline__ double row_al(int t) {
+    return (t == R_SLO) ? -1.0 : ((t == R_SHI || t == R_SAFE1 || t == R_SAFE2 || t == R_HWP) ? 1.0 : 0.0);
+}
+__device__ __forceinline__ double row_be(int t, double tau_min, double chw) {
+    switch (t) {
+        case R_VLO: case R_VINC: return -1.0;
+        case R_VHI: case R_VLIM: case R_VCURV: case R_VSTOP: case R_VTL: return 1.0;
+        case R_SAFE2: return tau_min;
+        case R_HWP: return chw;
+        default: return 0.0;
+    }
+}
+__device__ __forceinline__ double row_ga(int t) {
+    return (t == R_AMAX || t == R_JMAX) ? 1.0 : ((t == R_AMIN || t == R_JMIN) ? -1.0 : 0.0);
+}
+__device__ __forceinline__ double row_de(int t, int k) {
+    if (k == 0) return 0.0;
+    return t == R_JMAX ? -1.0 : (t == R_JMIN ? 1.0 : 0.0);
+}
+
+template <int MMAX>
+struct WaveMem {                 // one per wave, in LDS
+    double P[MMAX * (MMAX + 1) / 2];
+    double yv[64], ub[64], av[64];
+    double sub[65], vub[65], shv[65], vhv[65];
+    double ws[65], wv[65], wa[65];
+    double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX], e_D[MMAX];
+    double lam[MMAX], sv[MMAX], rv[MMAX], colk[MMAX];
+    int w_k[MMAX];
+};
+
+__device__ __forceinline__ int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// per-lane (= per-stage) registers of the wave's QP
+struct Lane {
+    int lane, N;
+    double T, tau, tau1;          // T_k, tau_k, tau_{k+1}
+    double ba[kNumRowTypes];      // a-space right-hand sides
+    unsigned valid;               // bit t: row (t, lane) exists with a non-zero normal
+    double lbF, lbS, lbV, lbH;    // slack lower bounds (constant rows of stage 0 fold in here)
+    unsigned long long code;      // 4 bits per type: 0 off, 1 in working set, 2 group pivot, 3 compliant
+    double chw;                   // headway-policy coefficient T_hwp + G_hwp*v_est(k)
+    double g0;                    // base gradient of the condensed objective
+    double a, sh, vh, am1;        // acceleration and homogeneous trajectories, a_{k-1}
+    double lamt[kNumRowTypes], rt[kNumRowTypes];
+    int base;                     // first working-set position of this lane's rows
+};
+
+__device__ __forceinline__ int code_of(const Lane& L, int t) { return (int)((L.code >> (4 * t)) & 15ull); }
+__device__ __forceinline__ void set_code(Lane& L, int t, int c) {
+    L.code = (L.code & ~(15ull << (4 * t))) | ((unsigned long long)c << (4 * t));
+}
+
+struct Cfg {   // wave-uniform scalars pulled out of DevCfg once
+    int N;
+    double tau_min, wF, wS, wV, wH, qH;
+};
+
+__device__ __forceinline__ double group_w(const Cfg& c, int g) {
+    return g == G_F ? c.wF : (g == G_S ? c.wS : (g == G_V ? c.wV : c.wH));
+}
+__device__ __forceinline__ double group_lb(const Lane& L, int g) {
+    return g == G_F ? L.lbF : (g == G_S ? L.lbS : (g == G_V ? L.lbV : L.lbH));
+}
+__device__ __forceinline__ int lane_group(const Lane& L, int t) { return L.lane == L.N ? G_NONE : group_of(t); }
+
+// value of row t at this lane for the current homogeneous trajectory (without slack)
+__device__ __forceinline__ double row_val(const Lane& L, const Cfg& c, int t, double ba_t) {
+    return row_al(t) * L.sh + row_be(t, c.tau_min, L.chw) * L.vh + row_ga(t) * L.a + row_de(t, L.lane) * L.am1 - ba_t;
+}
+
+// pivot type of linear group g at this lane (-1 if the group is in Z state)
+__device__ __forceinline__ int pivot_of(const Lane& L, int g) {
+    int p = -1;
+#pragma unroll
+    for (int t = R_AMAX; t <= R_VINC; ++t)
+        if (group_of(t) == g && code_of(L, t) == 2) p = t;
+    return p;
+}
+
+// homogeneous double-integrator response to the per-lane input x (lane k < N holds x_k):
+//   vh_k = sum_{i<k} T_i x_i ,  sh_k = sum_{i<k} (T_i vh_i + T_i^2/2 x_i)
+__device__ __forceinline__ void hom_traj(const Lane& L, double x, double& sh, double& vh) {
+    double xi = (L.lane < L.N) ? x : 0.0;
+    vh = scan_excl(L.T * xi);
+    double inc = (L.lane < L.N) ? (L.T * vh + 0.5 * L.T * L.T * xi) : 0.0;
+    sh = scan_excl(inc);
+}
+
+// out_k = sum_i Hinv[i][k] * yv[i]   (Hinv symmetric, table in LDS, yv in LDS)
+__device__ __forceinline__ double hinv_mul(const double* __restrict__ Hs, const double* yv, int N, int lane) {
+    double acc = 0.0;
+    const int k = lane < N ? lane : 0;
+    for (int i = 0; i < N; ++i) acc = fma(Hs[i * N + k], yv[i], acc);
+    return lane < N ? acc : 0.0;
+}
+
+// a-space normal of the row (kq; al,be,ga,de) evaluated at this lane j:
+__device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, double be, double ga, double de, double tau_kq) {
+    double c = 0.0;
+    const int j = L.lane;
+    if (j < L.N) {
+        if (j < kq) c = L.T * (be + al * (0.5 * L.T + tau_kq - L.tau1));
+        if (j == kq) c += ga;
+        if (j == kq - 1) c += de;
+    }
+    return c;
+}
+
+// adjoint of the condensing: given stage weights on (s_k, v_k, a_k) in LDS (ws, wv, wa, k = 0..N)
+// returns d/da_j of sum_k ws_k s_k + wv_k v_k + wa_k a_k  for lane j < N
+__device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, const double* wa) {
+    const int j = L.lane;
+    const bool in = j <= L.N;
+    double s = in ? ws[j] : 0.0, v = in ? wv[j] : 0.0;
+    double WS = suffix_excl(s);
+    double WV = suffix_excl(v);
+    double WST = suffix_excl(s * L.tau);
+    double g = 0.0;
+    if (j < L.N) g = wa[j] + L.T * (WV + WST - (L.tau1 - 0.5 * L.T) * WS);
+    return g;
+}
+
+enum Ev : int { EV_NONE = 0, EV_DROP, EV_COMPL, EV_RIGID, EV_CAP, EV_CAPIN };
+
+struct SolveStats { int status, iters, events, m; };
+
+// ----------------------------------------------------------------------------------------------
+// rebuild the working-set list + effective rows from the state codes, build S = C Hinv C' + D,
+// invert it in place (symmetric sweeps).  returns m (or -1 if S was numerically singular).
+template <int MMAX>
+__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, const double* tauv) {
+    const int lane = L.lane, N = L.N;
+    // count this lane's active rows
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        int cd = code_of(L, t);
+        cnt += (cd == 1 || cd == 3) ? 1 : 0;
+    }
+    double basef = scan_excl((double)cnt);
+    L.base = (int)(basef + 0.5);
+    int m = (int)(wave_sum((double)cnt) + 0.5);
+    if (m > MMAX) return -2;
+    const int pF = pivot_of(L, G_F), pS = pivot_of(L, G_S), pV = pivot_of(L, G_V);
+    int pos = L.base;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        int cd = code_of(L, t);
+        if (cd == 1 || cd == 3) {
+            int g = lane_group(L, t);
+            double al = row_al(t), be = row_be(t, c.tau_min, L.chw), ga = row_ga(t), de = row_de(t, lane);
+            double d = L.ba[t], D = 0.0;
+            if (g == G_H) {
+                if (cd == 3) { d -= c.wH / c.qH; D = 1.0 / c.qH; }
+                else d += L.lbH;
+            } else if (g != G_NONE) {
+                int p = (g == G_F) ? pF : (g == G_S ? pS : pV);
+                if (p >= 0) {
+                    double pba = 0.0;
+#pragma unroll
+                    for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+                    al -= row_al(p); be -= row_be(p, c.tau_min, L.chw); ga -= row_ga(p); de -= row_de(p, lane);
+                    d -= pba;
+                } else {
+                    d += group_lb(L, g);
+                }
+            }
+            M.e_al[pos] = al; M.e_be[pos] = be; M.e_ga[pos] = ga; M.e_de[pos] = de;
+            M.e_d[pos] = d; M.e_D[pos] = D; M.w_k[pos] = lane;
+            ++pos;
+        }
+    }
+    WSYNC();
+    if (m == 0) return 0;
+    // S columns
+    for (int j = 0; j < m; ++j) {
+        const int kj = M.w_k[j];
+        const double al = M.e_al[j], be = M.e_be[j], ga = M.e_ga[j], de = M.e_de[j];
+        double cj = normal_at(L, kj, al, be, ga, de, tauv[kj]);
+        if (lane < N) M.yv[lane] = cj;
+        WSYNC();
+        double u = hinv_mul(Hs, M.yv, N, lane);
+        double su, vu;
+        hom_traj(L, u, su, vu);
+        if (lane < N) M.ub[lane] = u;
+        if (lane <= N) { M.sub[lane] = su; M.vub[lane] = vu; }
+        WSYNC();
+        if (lane >= j && lane < m) {
+            const int ki = M.w_k[lane];
+            double s = M.e_al[lane] * M.sub[ki] + M.e_be[lane] * M.vub[ki];
+            if (ki < N) s += M.e_ga[lane] * M.ub[ki];
+            if (ki > 0 && ki <= N) s += M.e_de[lane] * M.ub[ki - 1];
+            if (lane == j) s += M.e_D[lane];
+            M.P[pidx(lane, j)] = s;
+        }
+        WSYNC();
+    }
+    // in-place inversion by symmetric sweeps: after sweeping every pivot P = -S^-1
+    int singular = 0;
+    double scale = 0.0;
+    if (lane < m) scale = fabs(M.P[pidx(lane, lane)]);
+    {
+        int dummy = lane;
+        wave_argmax(scale, dummy);
+    }
+    for (int k = 0; k < m; ++k) {
+        const double d = M.P[pidx(k, k)];
+        if (!(d > 1e-13 * scale)) { singular = 1; break; }
+        const double inv = 1.0 / d;
+        if (lane < m) M.colk[lane] = M.P[pidx(lane, k)];
+        WSYNC();
+        for (int r = 0; r < m; ++r) {
+            if (lane <= r) {
+                double v;
+                if (r == k && lane == k) v = -inv;
+                else if (r == k) v = M.colk[lane] * inv;          // (k, lane), lane < k
+                else if (lane == k) v = M.colk[r] * inv;          // (r, k), r > k
+                else v = M.P[pidx(r, lane)] - M.colk[r] * M.colk[lane] * inv;
+                M.P[pidx(r, lane)] = v;
+            }
+        }
+        WSYNC();
+    }
+    if (singular) return -1;
+    for (int r = 0; r < m; ++r)
+        if (lane <= r) M.P[pidx(r, lane)] = -M.P[pidx(r, lane)];
+    WSYNC();
+    return m;
+}
+
+// gradient-side vector: g_eff + (incoming multiplier) * c_q + C' lam   evaluated per lane
+template <int MMAX>
+__device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, WaveMem<MMAX>& M, int m, bool with_lam,
+                                double lam_q, int kq, double qal, double qbe, double qga, double qde) {
+    const int lane = L.lane, N = L.N;
+    // pivot rows act like working-set rows with multiplier w_g (own stage: plain stores)
+    double s = 0.0, v = 0.0, a0 = 0.0, a1 = 0.0;   // a1 -> stage lane-1
+    if (lane < N) {
+#pragma unroll
+        for (int t = R_AMAX; t <= R_VINC; ++t) {
+            if (code_of(L, t) == 2) {
+                double w = group_w(c, group_of(t));
+                s += w * row_al(t); v += w * row_be(t, c.tau_min, L.chw);
+                a0 += w * row_ga(t); a1 += w * row_de(t, lane);
+            }
+        }
+    }
+    if (lane <= N) { M.ws[lane] = s; M.wv[lane] = v; M.wa[lane] = a0; }
+    WSYNC();
+    if (lane > 0 && lane < N && a1 != 0.0) atomicAdd(&M.wa[lane - 1], a1);
+    if (with_lam && lane < m) {
+        const int ki = M.w_k[lane];
+        const double l = M.lam[lane];
+        atomicAdd(&M.ws[ki], l * M.e_al[lane]);
+        atomicAdd(&M.wv[ki], l * M.e_be[lane]);
+        if (ki < N && M.e_ga[lane] != 0.0) atomicAdd(&M.wa[ki], l * M.e_ga[lane]);
+        if (ki > 0 && M.e_de[lane] != 0.0) atomicAdd(&M.wa[ki - 1], l * M.e_de[lane]);
+    }
+    if (lam_q != 0.0 && lane == 0) {
+        atomicAdd(&M.ws[kq], lam_q * qal);
+        atomicAdd(&M.wv[kq], lam_q * qbe);
+        if (kq < N && qga != 0.0) atomicAdd(&M.wa[kq], lam_q * qga);
+        if (kq > 0 && qde != 0.0) atomicAdd(&M.wa[kq - 1], lam_q * qde);
+    }
+    WSYNC();
+    double g = adjoint(L, M.ws, M.wv, M.wa);
+    return (lane < N) ? g + L.g0 : 0.0;
+}
+
+// C x for the working-set rows (x given through its LDS images ub/sub/vub): result for lane i < m
+template <int MMAX>
+__device__ __forceinline__ double rows_dot(const WaveMem<MMAX>& M, int i, int N) {
+    const int ki = M.w_k[i];
+    double s = M.e_al[i] * M.sub[ki] + M.e_be[i] * M.vub[ki];
+    if (ki < N) s += M.e_ga[i] * M.ub[ki];
+    if (ki > 0) s += M.e_de[i] * M.ub[ki - 1];
+    return s;
+}
+
+// lam = -P (d + C h (+ nothing else)); h given through ub/sub/vub
+template <int MMAX>
+__device__ __forceinline__ void solve_multipliers(WaveMem<MMAX>& M, int m, int lane, int N) {
+    if (lane < m) M.sv[lane] = M.e_d[lane] + rows_dot(M, lane, N);
+    WSYNC();
+    if (lane < m) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc = fma(M.P[pidx(lane, j)], M.sv[j], acc);
+        M.lam[lane] = -acc;
+    }
+    WSYNC();
+}
+
+// scatter working-set vector x[pos] back to the owning (lane, type) registers
+template <int MMAX>
+__device__ __forceinline__ void scatter_to_types(const Lane& L, const double* x, double* out) {
+    int pos = L.base;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        int cd = code_of(L, t);
+        double v = 0.0;
+        if (cd == 1 || cd == 3) { v = x[pos]; ++pos; }
+        out[t] = v;
+    }
+}
+
+// primal point from the multipliers: a = -Hinv (g_eff + lam_q c_q + C' lam); also refreshes the
+// homogeneous trajectories and their LDS images (av/shv/vhv)
+template <int MMAX>
+__device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, int m,
+                                        double lam_q, int kq, double qal, double qbe, double qga, double qde,
+                                        double& grad_total) {
+    double g = gradient_side(L, c, M, m, true, lam_q, kq, qal, qbe, qga, qde);
+    grad_total = g;
+    if (L.lane < L.N) M.yv[L.lane] = g;
+    WSYNC();
+    L.a = -hinv_mul(Hs, M.yv, L.N, L.lane);
+    hom_traj(L, L.a, L.sh, L.vh);
+    L.am1 = __shfl_up(L.a, 1, 64);
+    if (L.lane == 0) L.am1 = 0.0;
+    if (L.lane < L.N) M.av[L.lane] = L.a;
+    if (L.lane <= L.N) { M.shv[L.lane] = L.sh; M.vhv[L.lane] = L.vh; }
+    WSYNC();
+}
+
+// slack of linear group g at this lane for the current point
+__device__ __forceinline__ double group_xi(const Lane& L, const Cfg& c, int g) {
+    int p = pivot_of(L, g);
+    if (p < 0) return group_lb(L, g);
+    double pba = 0.0;
+#pragma unroll
+    for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+    return row_val(L, c, p, pba);
+}
+
+// ----------------------------------------------------------------------------------------------
+// the dual active-set solve.  On entry L.code holds the (warm) working set; on exit the optimal
+// one, L.a the accelerations, L.lamt the multipliers per (lane, type).
+template <int MMAX>
+__device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, const double* tauv,
+                               int max_iter, double& grad_total) {
+    const int lane = L.lane, N = L.N;
+    SolveStats st{0, 0, 0, 0};
+    int m = 0;
+    // ---- warm start: make the shifted working set dual feasible -------------------------
+    {
+        bool ok = false;
+        for (int pass = 0; pass < 6 && !ok; ++pass) {
+            m = rebuild_and_factor(L, c, M, Hs, tauv);
+            if (m < 0) break;
+            if (m == 0) { ok = true; break; }
+            // h = Hinv g_eff
+            double g = gradient_side(L, c, M, 0, false, 0.0, 0, 0, 0, 0, 0);
+            if (lane < N) M.yv[lane] = g;
+            WSYNC();
+            double h = hinv_mul(Hs, M.yv, N, lane);
+            double shh, vhh;
+            hom_traj(L, h, shh, vhh);
+            if (lane < N) M.ub[lane] = h;
+            if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
+            WSYNC();
+            solve_multipliers(M, m, lane, N);
+            scatter_to_types<MMAX>(L, M.lam, L.lamt);
+            // repair
+            int changed = 0;
+            double sumF = 0.0, sumS = 0.0, sumV = 0.0;
+#pragma unroll
+            for (int t = 0; t < kNumRowTypes; ++t) {
+                int cd = code_of(L, t);
+                if (cd != 1 && cd != 3) continue;
+                int g2 = lane_group(L, t);
+                double l = L.lamt[t];
+                if (g2 == G_H) {
+                    if (cd == 3) { if (l < c.wH - kTolDual) { set_code(L, t, 1); changed = 1; } }
+                    else if (l < -kTolDual) { set_code(L, t, 0); changed = 1; }
+                    else if (l > c.wH + kTolDual) { set_code(L, t, 3); changed = 1; }
+                } else {
+                    if (l < -kTolDual) { set_code(L, t, 0); changed = 1; l = 0.0; }
+                    if (g2 == G_F) sumF += l; else if (g2 == G_S) sumS += l; else if (g2 == G_V) sumV += l;
+                }
+            }
+            int any = __any(changed);
+            if (!any) {
+                // group margins (bound multiplier in Z, pivot multiplier in P)
+#pragma unroll
+                for (int g2 = G_F; g2 <= G_V; ++g2) {
+                    double sum = g2 == G_F ? sumF : (g2 == G_S ? sumS : sumV);
+                    double w = group_w(c, g2);
+                    if (lane < N && w - sum < -kTolDual * (1.0 + w)) {
+                        changed = 1;
+                        int p = pivot_of(L, g2);
+                        if (p >= 0) set_code(L, p, 0);
+                        int best = -1; double bl = -1.0;
+#pragma unroll
+                        for (int t = R_AMAX; t <= R_VINC; ++t)
+                            if (group_of(t) == g2 && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; best = t; }
+                        if (best >= 0) set_code(L, best, 2);
+                    }
+                }
+                any = __any(changed);
+            }
+            if (!any) ok = true;
+        }
+        if (!ok) {
+            L.code = 0ull;           // cold start
+            m = rebuild_and_factor(L, c, M, Hs, tauv);
+        }
+    }
+    // ---- main loop -------------------------------------------------------------------------
+    const double* none = nullptr; (void)none;
+    for (;;) {
+        primal_from_multipliers(L, c, M, Hs, m, 0.0, 0, 0, 0, 0, 0, grad_total);
+        // most violated inactive row / group bound
+        double best = kTolViol; int bp = -1;
+        {
+            double xiF = 0, xiS = 0, xiV = 0;
+            if (lane < N) { xiF = group_xi(L, c, G_F); xiS = group_xi(L, c, G_S); xiV = group_xi(L, c, G_V); }
+            double myb = kTolViol; int myp = -1;
+#pragma unroll
+            for (int t = 0; t < kNumRowTypes; ++t) {
+                if (!((L.valid >> t) & 1u)) continue;
+                if (code_of(L, t) != 0) continue;
+                int g2 = lane_group(L, t);
+                double val = row_val(L, c, t, L.ba[t]);
+                val -= (g2 == G_F) ? xiF : (g2 == G_S ? xiS : (g2 == G_V ? xiV : (g2 == G_H ? L.lbH : 0.0)));
+                double sc = val / (1.0 + fabs(L.ba[t]));
+                if (sc > myb) { myb = sc; myp = t; }
+            }
+            if (lane < N) {
+                if (pivot_of(L, G_F) >= 0 && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 16 + G_F; }
+                if (pivot_of(L, G_S) >= 0 && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 16 + G_S; }
+                if (pivot_of(L, G_V) >= 0 && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
+            }
+            best = myb; bp = (myp < 0) ? 0x7fffffff : (lane * 32 + myp);
+            wave_argmax(best, bp);
+            if (bp == 0x7fffffff) bp = -1;
+        }
+        if (bp < 0) break;
+        if (++st.iters > max_iter) { st.status = 2; break; }
+        const int kq = bp >> 5, qcode = bp & 31;
+        const bool q_is_bound = qcode >= 16;
+        const int tq = q_is_bound ? -1 : qcode;
+        const int gq = q_is_bound ? (qcode - 16) : ((kq == N) ? G_NONE : group_of(qcode));
+        double lam_q = 0.0;
+        bool inc_compl = false;
+        bool finished = false;
+        while (!finished) {
+            if (++st.events > 40 * max_iter) { st.status = 2; finished = true; break; }
+            // effective incoming row (computed on lane kq, broadcast)
+            double qal = 0, qbe = 0, qga = 0, qde = 0, qd = 0, qD = 0;
+            if (lane == kq) {
+                if (!q_is_bound) {
+                    qal = row_al(tq); qbe = row_be(tq, c.tau_min, L.chw); qga = row_ga(tq); qde = row_de(tq, lane);
+                    double bq = 0.0;
+#pragma unroll
+                    for (int u = 0; u < kNumRowTypes; ++u) if (u == tq) bq = L.ba[u];
+                    qd = bq;
+                    if (gq == G_H) {
+                        if (inc_compl) { qd -= c.wH / c.qH; qD = 1.0 / c.qH; } else qd += L.lbH;
+                    } else if (gq != G_NONE) {
+                        int p = pivot_of(L, gq);
+                        if (p >= 0) {
+                            double pba = 0.0;
+#pragma unroll
+                            for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+                            qal -= row_al(p); qbe -= row_be(p, c.tau_min, L.chw); qga -= row_ga(p); qde -= row_de(p, lane);
+                            qd -= pba;
+                        } else qd += group_lb(L, gq);
+                    }
+                } else {
+                    int p = pivot_of(L, gq);
+                    double pba = 0.0;
+#pragma unroll
+                    for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+                    qal = -row_al(p); qbe = -row_be(p, c.tau_min, L.chw); qga = -row_ga(p); qde = -row_de(p, lane);
+                    qd = -(pba + group_lb(L, gq));
+                }
+            }
+            qal = bcast(qal, kq); qbe = bcast(qbe, kq); qga = bcast(qga, kq); qde = bcast(qde, kq);
+            qd = bcast(qd, kq); qD = bcast(qD, kq);
+            // multipliers of the working set for the current incoming multiplier
+            m = rebuild_and_factor(L, c, M, Hs, tauv);
+            if (m < 0) { st.status = 2; finished = true; break; }
+            {
+                double g = gradient_side(L, c, M, 0, false, lam_q, kq, qal, qbe, qga, qde);
+                if (lane < N) M.yv[lane] = g;
+                WSYNC();
+                double h = hinv_mul(Hs, M.yv, N, lane);
+                double shh, vhh;
+                hom_traj(L, h, shh, vhh);
+                if (lane < N) M.ub[lane] = h;
+                if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
+                WSYNC();
+                if (m > 0) solve_multipliers(M, m, lane, N);
+            }
+            primal_from_multipliers(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total);
+            double viol = qal * M.shv[kq] + qbe * M.vhv[kq] - qD * lam_q - qd;
+            if (kq < N) viol += qga * M.av[kq];
+            if (kq > 0) viol += qde * M.av[kq - 1];
+            // u = Hinv c_q and its trajectories
+            double cj = normal_at(L, kq, qal, qbe, qga, qde, tauv[kq]);
+            if (lane < N) M.yv[lane] = cj;
+            WSYNC();
+            double u = hinv_mul(Hs, M.yv, N, lane);
+            double su, vu;
+            hom_traj(L, u, su, vu);
+            if (lane < N) M.ub[lane] = u;
+            if (lane <= N) { M.sub[lane] = su; M.vub[lane] = vu; }
+            WSYNC();
+            double cu = qal * M.sub[kq] + qbe * M.vub[kq];
+            if (kq < N) cu += qga * M.ub[kq];
+            if (kq > 0) cu += qde * M.ub[kq - 1];
+            double sr = 0.0;
+            if (m > 0) {
+                if (lane < m) M.sv[lane] = rows_dot(M, lane, N);
+                WSYNC();
+                double r = 0.0;
+                if (lane < m) {
+                    for (int j = 0; j < m; ++j) r = fma(M.P[pidx(lane, j)], M.sv[j], r);
+                    M.rv[lane] = r;
+                    sr = M.sv[lane] * r;
+                }
+                WSYNC();
+                sr = wave_sum(sr);
+            }
+            const double zz = cu - sr + qD;
+            double t2 = (zz > 1e-13 * (1.0 + cu)) ? viol / zz : kInf;
+            if (viol <= 0.0) t2 = 0.0;
+            // blocking events, evaluated per (lane, type)
+            scatter_to_types<MMAX>(L, M.lam, L.lamt);
+            scatter_to_types<MMAX>(L, M.rv, L.rt);
+            double t1 = kInf; int ev = 0x7fffffff;
+            {
+                double sumLF = 0, sumLS = 0, sumLV = 0, sumRF = 0, sumRS = 0, sumRV = 0;
+#pragma unroll
+                for (int t = 0; t < kNumRowTypes; ++t) {
+                    int cd = code_of(L, t);
+                    if (cd != 1 && cd != 3) continue;
+                    int g2 = lane_group(L, t);
+                    double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
+                    if (g2 == G_H) {
+                        if (cd == 3) {
+                            if (r > 0.0) { double tt = fmax(l - c.wH, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_RIGID << 16) | (lane << 5) | t; } }
+                        } else {
+                            if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                            else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
+                        }
+                    } else {
+                        if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                        if (g2 == G_F) { sumLF += l; sumRF += r; } else if (g2 == G_S) { sumLS += l; sumRS += r; } else if (g2 == G_V) { sumLV += l; sumRV += r; }
+                    }
+                }
+                if (lane < N) {
+#pragma unroll
+                    for (int g2 = G_F; g2 <= G_V; ++g2) {
+                        double sl = g2 == G_F ? sumLF : (g2 == G_S ? sumLS : sumLV);
+                        double srr = g2 == G_F ? sumRF : (g2 == G_S ? sumRS : sumRV);
+                        double rate = -srr, margin = group_w(c, g2) - sl;
+                        if (lane == kq && gq == g2) { rate += 1.0; margin -= lam_q; }
+                        if (rate > 0.0) {
+                            double tt = fmax(margin, 0.0) / rate;
+                            if (tt < t1) { t1 = tt; ev = (EV_CAP << 16) | (lane << 5) | g2; }
+                        }
+                    }
+                }
+                if (lane == kq && !q_is_bound && gq == G_H && !inc_compl) {
+                    double tt = fmax(c.wH - lam_q, 0.0);
+                    if (tt < t1) { t1 = tt; ev = (EV_CAPIN << 16) | (lane << 5); }
+                }
+                wave_argmin(t1, ev);
+            }
+            const double tstep = fmin(t1, t2);
+            if (!(tstep < 1e299)) { st.status = 1; finished = true; break; }
+            lam_q += tstep;
+            if (t2 <= t1) {
+                // full step: the incoming constraint becomes active
+                if (lane == kq) {
+                    if (!q_is_bound) set_code(L, tq, inc_compl ? 3 : 1);
+                    else { int p = pivot_of(L, gq); set_code(L, p, 1); }
+                }
+                finished = true;
+            } else {
+                const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
+                if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
+                else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
+                else if (ek == EV_RIGID) { if (lane == el) set_code(L, et, 1); }
+                else if (ek == EV_CAPIN) { inc_compl = true; }
+                else if (ek == EV_CAP) {
+                    int fin = 0;
+                    if (lane == el) {
+                        const int g2 = et;
+                        // members (code 1) of the group with their multipliers after the step
+                        int bestm = -1; double bl = -1e300;
+#pragma unroll
+                        for (int t = R_AMAX; t <= R_VINC; ++t)
+                            if (group_of(t) == g2 && code_of(L, t) == 1) {
+                                double l = L.lamt[t] - tstep * ((m > 0) ? L.rt[t] : 0.0);
+                                if (l > bl) { bl = l; bestm = t; }
+                            }
+                        const int p = pivot_of(L, g2);
+                        const bool q_row_here = (kq == el) && !q_is_bound && gq == g2;
+                        const bool q_bound_here = (kq == el) && q_is_bound && gq == g2;
+                        if (p < 0) {                       // Z -> P
+                            if (bestm < 0) { set_code(L, tq, 2); fin = 1; }
+                            else set_code(L, bestm, 2);
+                        } else {                           // pivot multiplier reached zero
+                            set_code(L, p, 0);
+                            if (bestm >= 0) set_code(L, bestm, 2);
+                            else if (q_row_here) { set_code(L, tq, 2); fin = 1; }
+                            else if (q_bound_here) { fin = 1; }
+                        }
+                    }
+                    if (__any(fin)) finished = true;
+                }
+            }
+        }
+        if (st.status != 0) break;
+        m = rebuild_and_factor(L, c, M, Hs, tauv);
+        if (m < 0) { st.status = 2; break; }
+        if (m > 0) {
+            double g = gradient_side(L, c, M, 0, false, 0.0, 0, 0, 0, 0, 0);
+            if (lane < N) M.yv[lane] = g;
+            WSYNC();
+            double h = hinv_mul(Hs, M.yv, N, lane);
+            double shh, vhh;
+            hom_traj(L, h, shh, vhh);
+            if (lane < N) M.ub[lane] = h;
+            if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
+            WSYNC();
+            solve_multipliers(M, m, lane, N);
+        }
+    }
+    scatter_to_types<MMAX>(L, M.lam, L.lamt);
+    st.m = m;
+    return st;
+}
+
+// ----------------------------------------------------------------------------------------------
+// per-step set-up: estimator, bounds, right-hand sides (A2, A3, A4 of SURVEY.md section 8a)
+
+struct StepIn { double s, v, a_prev, t0, s_tv, v_tv, a_tv_prev; };
+
+// ABO/Functions/MPCs/EstimateVehicleTrajectory.m:55-80 (modes 0 and 1), value for stage `lane`
+__device__ void estimate_traj(const DevCfg& C, int mode, double tConstACC, double s0, double v0, double a0,
+                              int lane, double& s_est, double& v_est) {
+    const int N = C.N;
+    const int i = lane <= N ? lane : N;
+    if (mode == 0) {
+        s_est = s0 + C.tau[i] * v0;      // sum_{j<i} Tvec[j]*v0 (one rounding vs repeated adds)
+        v_est = v0;
+        return;
+    }
+    // mode 1: constant acceleration for the first steps, sequentially as the reference does
+    double s = s0, v = v0, ms = s0, mv = v0;
+    int last = 0;
+    for (int j = 1; j <= N; ++j) {
+        const double Ts = C.Tvec[j - 1];
+        const bool idx_ok = (double)(j + 1) <= tConstACC / Ts;
+        if (!idx_ok && C.const_T) break;
+        const double vprev = v;
+        if (idx_ok && v + Ts * a0 > 0.0) v = v + Ts * a0;
+        s = s + Ts * vprev;
+        last = j;
+        if (j == i) { ms = s; mv = v; }
+    }
+    if (i > last) {
+        // remaining stages: constant velocity v from stage `last` on
+        mv = v;
+        ms = s + v * (C.tau[i] - C.tau[last]);
+    }
+    s_est = ms; v_est = mv;
+}
+
+// ABO/Functions/MPCs/EstimateRouteAndComfortBounds.m:89-171 for one stage
+__device__ void route_bounds(const DevCfg& C, double s_est, double v_est, double t0, int i /*0-based stage*/,
+                             double& v_lim, double& v_curv, double& v_stop, double& v_TL,
+                             double& a_min, double& a_max, double& j_min, double& j_max) {
+    v_lim = 0.0;
+    for (int j = 0; j < C.n_speedLim; ++j) {
+        if (j == C.n_speedLim - 1) v_lim = C.s_speedLim[C.n_speedLim - 1];     // sic (:93)
+        else if (s_est >= C.s_speedLim[j] && s_est < C.s_speedLim[j + 1]) { v_lim = C.v_speedLim[j]; break; }
+    }
+    v_curv = 0.0;
+    for (int j = 0; j < C.n_curv; ++j) {
+        if (j == C.n_curv - 1) v_curv = C.vcurv_tab[C.n_curv - 1];
+        else if (s_est > C.s_curv[j] && s_est < C.s_curv[j + 1]) { v_curv = C.vcurv_tab[j]; break; }
+    }
+    v_stop = 1e5;
+    for (int j = 0; j < C.n_stop; ++j) {
+        double dist = fabs(C.stopLoc[j] - s_est);
+        if (dist < C.stopRefDist) v_stop = dist * C.stopRefVelSlope + C.stopVel;
+    }
+    v_TL = 1e5;
+    for (int j = 0; j < C.n_TL; ++j) {
+        const double* TL = &C.TLLoc[4 * j];
+        double x = t0 + (double)(i + 1) * C.Tvec[i] - TL[1];
+        double mm = TL[2] + TL[3];
+        double md = (mm == 0.0) ? x : x - floor(x / mm) * mm;
+        if (md < TL[2]) {
+            double d = TL[0] - s_est;
+            if (fabs(d) < C.stopRefDist) {
+                if (d < 0.0) v_TL = fabs(d) * C.stopRefVelSlope + C.TLstopVel;
+                else if (fabs(d) < C.TLStopRegionSize) v_TL = C.TLstopVel;
+                else v_TL = fabs(d - C.stopVel) * C.stopRefVelSlope + C.TLstopVel;
+            }
+        }
+    }
+    if (v_est < 5.0) { a_min = -5.0; a_max = 4.0; j_min = -5.0; j_max = 5.0; }
+    else if (v_est < 20.0) {
+        a_min = -5.5 + v_est / 10.0; a_max = 14.0 / 3.0 - 2.0 * v_est / 15.0;
+        j_min = -35.0 / 6.0 + v_est / 6.0; j_max = 35.0 / 6.0 - v_est / 6.0;
+    } else { a_min = -3.5; a_max = 2.0; j_min = -2.5; j_max = 2.5; }
+}
+
+// ABO/Functions/PWA_function_manipulation/InterpPWA.m:14-27
+__device__ double interp_pwa(double d, const double* doms, const double* vals, int n) {
+    if (d < doms[0]) return vals[0];
+    if (d > doms[n - 1]) return vals[n - 1];
+    for (int i = 0; i < n - 1; ++i)
+        if (d >= doms[i] && d <= doms[i + 1]) {
+            double f = (d - doms[i]) / (doms[i + 1] - doms[i]);
+            return vals[i] + f * (vals[i + 1] - vals[i]);
+        }
+    return vals[n - 1];
+}
+
+__device__ __forceinline__ void slope_trig(const DevCfg& C, double s, double& sn, double& cs) {
+    if (C.const_slope) { sn = C.sin_theta0; cs = C.cos_theta0; return; }
+    double th = interp_pwa(s, C.s_slope, C.slope, C.n_slope);
+    sn = sin(th); cs = cos(th);
+}
+
+// ABO/Functions/MPCs/RunPlantModel.m:27-44
+__device__ void plant_rk4(const DevCfg& C, double s, double v, double u, double& s1, double& v1) {
+    const int Mi = C.N_integratePlant;
+    const double DT = C.Tvec[0] / Mi;
+    const double ilm = 1.0 / C.lambda / C.m;
+    double x0 = s, x1 = v;
+    for (int k = 0; k < Mi; ++k) {
+        double sn, cs;
+        slope_trig(C, x0, sn, cs);
+        double k10 = x1, k11 = ilm * (u - C.zeta_a * x1 * x1 - C.c_r * C.m * C.g * cs - C.m * C.g * sn);
+        double y0 = x0 + DT / 2 * k10, y1 = x1 + DT / 2 * k11;
+        slope_trig(C, y0, sn, cs);
+        double k20 = y1, k21 = ilm * (u - C.zeta_a * y1 * y1 - C.c_r * C.m * C.g * cs - C.m * C.g * sn);
+        y0 = x0 + DT / 2 * k20; y1 = x1 + DT / 2 * k21;
+        slope_trig(C, y0, sn, cs);
+        double k30 = y1, k31 = ilm * (u - C.zeta_a * y1 * y1 - C.c_r * C.m * C.g * cs - C.m * C.g * sn);
+        y0 = x0 + DT * k30; y1 = x1 + DT * k31;
+        slope_trig(C, y0, sn, cs);
+        double k40 = y1, k41 = ilm * (u - C.zeta_a * y1 * y1 - C.c_r * C.m * C.g * cs - C.m * C.g * sn);
+        x0 = x0 + DT / 6 * (k10 + 2 * k20 + 2 * k30 + k40);
+        x1 = x1 + DT / 6 * (k11 + 2 * k21 + 2 * k31 + k41);
+    }
+    s1 = x0; v1 = x1;
+}
+
+// ABO/RunOpt_ABMPC.m:287-324
+__device__ void force_allocation(const DevCfg& C, double s_meas, double v_meas, double a_qp,
+                                 double& Fm, double& Fb, double& a_real) {
+    double sn, cs;
+    slope_trig(C, s_meas, sn, cs);
+    double F_r = -C.zeta_a * v_meas * v_meas - C.c_r * C.m * C.g * cs - C.m * C.g * sn;
+    double F_t_req = C.m * C.lambda * a_qp - F_r;
+    double F_f_r_max = C.mu / C.L * (C.m * C.g * (C.L_f * cs + C.h_g * sn) +
+                                     C.h_g * (C.zeta_a * v_meas * v_meas + C.lambda * C.m * a_qp));
+    double F_f_tot_max = C.mu * C.m * C.g * cs;
+    if (F_t_req < 0.0) {
+        double F_m_min = (v_meas < C.omega_m_r / C.phi) ? -C.phi * C.T_m_max / C.eta_TF : -C.P_m_max / C.eta_TF / v_meas;
+        double fm = fmax(fmax(F_t_req, F_m_min), -F_f_r_max);
+        Fm = fm;
+        Fb = fmax(F_t_req, -F_f_tot_max) - fm;
+    } else {
+        double F_m_max = (v_meas < C.omega_m_r / C.phi) ? C.phi * C.T_m_max * C.eta_TF : C.P_m_max * C.eta_TF / v_meas;
+        Fm = fmin(fmin(F_t_req, F_m_max), F_f_r_max);
+        Fb = 0.0;
+    }
+    a_real = (Fm + Fb + F_r) / C.m / C.lambda;
+}
+
+struct StepOut { double out[EEPACC_OUT_N]; int status, iters; };
+
+// One ABMPC step for the wave's instance (ABO/RunOpt_ABMPC.m:193-329).  `code` carries the
+// working set between steps (already shifted by the caller).
+template <int MMAX>
+__device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const double* Hs, const StepIn& in,
+                        unsigned long long& code, StepOut& so, double& s_pred, double& v_pred) {
+    Lane L;
+    L.lane = lane_id(); L.N = C.N;
+    const int lane = L.lane, N = C.N;
+    const int kk = lane <= N ? lane : N;
+    L.T = lane < N ? C.Tvec[lane] : 0.0;
+    L.tau = C.tau[kk];
+    L.tau1 = C.tau[kk + (lane < N ? 1 : 0)];
+    Cfg c;
+    c.N = N; c.tau_min = C.tau_min; c.wF = C.w_f; c.wS = C.w_s; c.wV = C.w_v; c.wH = 100.0 * C.w_h; c.qH = 2.0 * C.w_h;
+    // estimators (A2)
+    double s_est, v_est, stv_est, vtv_est;
+    estimate_traj(C, C.paramEstSetting, C.tConstACC_ego, in.s, in.v, in.a_prev, lane, s_est, v_est);
+    estimate_traj(C, C.TVestSetting, C.tConstACC_tar, in.s_tv, in.v_tv, in.a_tv_prev, lane, stv_est, vtv_est);
+    const double dist_hor = bcast(s_est, N) - in.s;                          // :200
+    const double stv_Nm1 = bcast(stv_est, N - 1);
+    // bounds (A3)
+    double v_lim, v_curv, v_stop, v_TL, a_min, a_max, j_min, j_max;
+    route_bounds(C, s_est, v_est, in.t0, lane < N ? lane : N - 1, v_lim, v_curv, v_stop, v_TL, a_min, a_max, j_min, j_max);
+    const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
+    L.chw = T_hwp + G_hwp * v_est;
+    // free response of the double integrator and a-space right-hand sides (A4 + A5)
+    const double sf = in.s + L.tau * in.v, vf = in.v;
+    double b[kNumRowTypes];
+    b[R_SLO] = -0.0; b[R_SHI] = C.s_goal; b[R_VLO] = -0.0; b[R_VHI] = C.v_max;
+    b[R_AMAX] = a_max; b[R_AMIN] = -a_min;
+    b[R_JMAX] = L.T * j_max + (lane == 0 ? in.a_prev : 0.0);
+    b[R_JMIN] = -(L.T * j_min + (lane == 0 ? in.a_prev : 0.0));
+    b[R_VLIM] = v_lim; b[R_VCURV] = v_curv; b[R_VSTOP] = v_stop; b[R_VTL] = v_TL;
+    b[R_VINC] = -fmin(v_lim, v_curv);
+    b[R_SAFE1] = stv_est - C.h_min; b[R_SAFE2] = stv_est; b[R_HWP] = stv_est - A_hwp;
+    if (lane == N) { b[R_SAFE1] = stv_Nm1 - C.h_min; b[R_SAFE2] = stv_Nm1; }
+    unsigned valid = 0u;
+    L.lbF = L.lbS = L.lbV = L.lbH = 0.0;
+    int infeasible_const = 0;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        double al = row_al(t), be = row_be(t, c.tau_min, L.chw);
+        L.ba[t] = b[t] - al * sf - be * vf;
+        bool exists;
+        if (lane < N) {
+            exists = true;
+            if (t == R_SHI && !(C.s_goal < 1e300)) exists = false;
+            if ((t == R_VLIM || t == R_VCURV || t == R_VSTOP || t == R_VTL) && !C.ab_route_rows) exists = false;
+        } else exists = (lane == N) && (t == R_SAFE1 || t == R_SAFE2);
+        if (exists && lane == 0 && row_ga(t) == 0.0) {
+            // stage-0 rows without an a-component are constants: fold into slack bounds
+            exists = false;
+            int g2 = group_of(t);
+            double need = -L.ba[t];
+            if (g2 == G_NONE) { if (need > 1e-9) infeasible_const = 1; }
+            else if (g2 == G_F) L.lbF = fmax(L.lbF, need);
+            else if (g2 == G_S) L.lbS = fmax(L.lbS, need);
+            else if (g2 == G_V) L.lbV = fmax(L.lbV, need);
+            else L.lbH = fmax(L.lbH, need);
+        }
+        if (exists) valid |= (1u << t);
+    }
+    L.valid = valid;
+    // drop warm-start codes of rows that do not exist at this lane
+    L.code = code;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t)
+        if (!((valid >> t) & 1u)) set_code(L, t, 0);
+    // base gradient (condensed objective, CreateQP_AB.m:162-180 through Psi'):
+    //   g_j = T_j * (N-1-j) * (2 cq v0 + w_FC p10) + w_FC p01 lambda m ; g_0 -= 2 w_j/T_0 a_{-1}
+    L.g0 = 0.0;
+    if (lane < N) {
+        L.g0 = L.T * (double)(N - 1 - lane) * (2.0 * C.cq * in.v + C.glin_v) + C.glin_a;
+        if (lane == 0) L.g0 -= 2.0 * C.w_j / L.T * in.a_prev;
+    }
+    L.a = L.sh = L.vh = L.am1 = 0.0;
+    double grad_total = 0.0;
+    SolveStats st = solve_qp<MMAX>(L, c, M, Hs, C.tau, C.max_iter, grad_total);
+    code = L.code;
+    // recover z = Psi x + d (A7): predicted states
+    s_pred = sf + L.sh; v_pred = vf + L.vh;
+    // stage-0 slacks and the dense-QP objective value
+    double xiF = 0, xiS = 0, xiV = 0, xiH = 0;
+    if (lane < N) {
+        xiF = fmax(group_xi(L, c, G_F), L.lbF);
+        xiS = fmax(group_xi(L, c, G_S), L.lbS);
+        xiV = fmax(group_xi(L, c, G_V), L.lbV);
+        xiH = (code_of(L, R_HWP) == 3) ? (L.lamt[R_HWP] - c.wH) / c.qH : L.lbH;
+    }
+    // 1/2 a'Ha + g'a with H a = -(grad_total - g0) - g0 ... : H a = -grad_total  => a'(g0 - grad/2)
+    double part = (lane < N) ? L.a * (L.g0 - 0.5 * grad_total) : 0.0;
+    part += C.w_f * xiF + C.w_s * xiS + C.w_v * xiV + c.wH * xiH + 0.5 * c.qH * xiH * xiH;
+    const double cost = wave_sum(part);
+    const double a0 = bcast(L.a, 0);
+    double Fm, Fb, a_real;
+    force_allocation(C, in.s, in.v, a0, Fm, Fb, a_real);
+    so.out[EEPACC_OUT_S] = in.s;
+    so.out[EEPACC_OUT_V] = in.v;
+    so.out[EEPACC_OUT_FM] = Fm;
+    so.out[EEPACC_OUT_FB] = Fb;
+    so.out[EEPACC_OUT_A] = a_real;
+    so.out[EEPACC_OUT_XI_V] = bcast(xiV, 0);
+    so.out[EEPACC_OUT_XI_H] = bcast(xiH, 0);
+    so.out[EEPACC_OUT_XI_S] = bcast(xiS, 0);
+    so.out[EEPACC_OUT_XI_F] = bcast(xiF, 0);
+    so.out[EEPACC_OUT_COST] = cost;
+    so.out[EEPACC_OUT_DISTHOR] = dist_hor;
+    so.out[EEPACC_OUT_AQP] = a0;
+    so.status = (st.status != 0 || __any(infeasible_const)) ? 1 : 0;
+    so.iters = st.iters;
+}
+
+// receding-horizon shift of the working set: stage k takes stage k+1's codes, the last stage and
+// the terminal rows keep theirs
+__device__ __forceinline__ unsigned long long shift_codes(unsigned long long code, int N) {
+    const int lane = lane_id();
+    unsigned lo = (unsigned)code, hi = (unsigned)(code >> 32);
+    unsigned nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
+    unsigned long long nxt = ((unsigned long long)nhi << 32) | nlo;
+    if (lane < N - 1) return nxt;
+    return code;
+}
+
+constexpr int kWavesPerBlock = 2;
+
+template <int MMAX>
+__device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, const double*& Hs) {
+    Hs = reinterpret_cast<const double*>(smem);
+    size_t off = ((size_t)N * N * sizeof(double) + 15) & ~(size_t)15;
+    return reinterpret_cast<WaveMem<MMAX>*>(smem + off) + (threadIdx.x >> 6);
+}
+
+__device__ __forceinline__ void load_hinv(unsigned char* smem, const DevCfg& C) {
+    double* Hs = reinterpret_cast<double*>(smem);
+    const int n2 = C.N * C.N;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) Hs[i] = C.Hinv[i];
+    __syncthreads();
+}
+
+// B2: one step for B instances.  state: per instance 64 x uint64 codes (instance-major).
+template <int MMAX>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+k_ab_step(const DevCfg* __restrict__ Cp, int B,
+          const double* __restrict__ s, const double* __restrict__ v, const double* __restrict__ a_prev,
+          const double* __restrict__ t0, const double* __restrict__ s_tv, const double* __restrict__ v_tv,
+          const double* __restrict__ a_tv_prev, unsigned long long* __restrict__ codes,
+          double* __restrict__ out, double* __restrict__ s_pred, double* __restrict__ v_pred,
+          int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DevCfg& C = *Cp;
+    load_hinv(smem, C);
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const double* Hs;
+    WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
+    const int lane = lane_id();
+    StepIn in{s[b], v[b], a_prev[b], t0[b], s_tv[b], v_tv[b], a_tv_prev[b]};
+    unsigned long long code = codes[(size_t)b * 64 + lane];
+    StepOut so;
+    double sp, vp;
+    ab_step<MMAX>(C, M, Hs, in, code, so, sp, vp);
+    codes[(size_t)b * 64 + lane] = shift_codes(code, C.N);
+    if (lane < EEPACC_OUT_N) {
+        double val = 0.0;
+#pragma unroll
+        for (int f = 0; f < EEPACC_OUT_N; ++f) if (f == lane) val = so.out[f];
+        out[(size_t)lane * B + b] = val;
+    }
+    if (s_pred && lane <= C.N) s_pred[(size_t)lane * B + b] = sp;
+    if (v_pred && lane <= C.N) v_pred[(size_t)lane * B + b] = vp;
+    if (lane == 0) { status[b] = so.status; if (iters) iters[b] = so.iters; }
+}
+
+// B1: closed loop over n_steps for B instances (ABO/RunOpt_ABMPC.m:154-340)
+template <int MMAX>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int n_steps,
+            const double* __restrict__ s0, const double* __restrict__ v0, const double* __restrict__ a_m1,
+            const double* __restrict__ s_tv, const double* __restrict__ v_tv,
+            double* __restrict__ traj, int32_t* __restrict__ status, int32_t* __restrict__ iters_total) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DevCfg& C = *Cp;
+    load_hinv(smem, C);
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const double* Hs;
+    WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
+    const int lane = lane_id();
+    const double Ts = C.Tvec[0];
+    unsigned long long code = 0ull;
+    double s_prev = 0, v_prev = 0, Fm_prev = 0, Fb_prev = 0, v_tv_measured = 0.0, t_0 = 0.0;
+    int it_total = 0;
+    for (int kk = 0; kk < n_steps; ++kk) {
+        StepIn in;
+        if (kk == 0) {                                       // :159-172
+            in.s = s0[b]; in.v = v0[b]; in.a_prev = a_m1[b];
+            in.s_tv = s_tv[b]; in.v_tv = 0.0; in.a_tv_prev = 0.0;
+            v_tv_measured = 0.0;
+        } else {                                             // :173-191
+            double sm, vm;
+            plant_rk4(C, s_prev, v_prev, Fm_prev + Fb_prev, sm, vm);
+            in.s = sm; in.v = vm;
+            in.a_prev = (vm - v_prev) / Ts;
+            in.s_tv = s_tv[(size_t)kk * B + b];
+            double v_tv_prev = v_tv_measured;
+            v_tv_measured = v_tv[(size_t)kk * B + b];
+            in.v_tv = v_tv_measured;
+            in.a_tv_prev = (v_tv_measured - v_tv_prev) / Ts;
+        }
+        in.t0 = t_0;
+        StepOut so;
+        double sp, vp;
+        ab_step<MMAX>(C, M, Hs, in, code, so, sp, vp);
+        code = shift_codes(code, C.N);
+        if (lane < EEPACC_OUT_N) {
+            double val = 0.0;
+#pragma unroll
+            for (int f = 0; f < EEPACC_OUT_N; ++f) if (f == lane) val = so.out[f];
+            traj[((size_t)kk * EEPACC_OUT_N + lane) * B + b] = val;
+        }
+        if (lane == 0) status[(size_t)kk * B + b] = so.status;
+        it_total += so.iters;
+        s_prev = so.out[EEPACC_OUT_S]; v_prev = so.out[EEPACC_OUT_V];
+        Fm_prev = so.out[EEPACC_OUT_FM]; Fb_prev = so.out[EEPACC_OUT_FB];
+        t_0 += Ts;                                           // :329
+    }
+    if (iters_total && lane == 0) iters_total[b] = it_total;
+}
+
+// A10: post-processing (ABO/RunOpt_ABMPC.m:343-349), one thread per instance, sequential in time
+__global__ void k_postprocess(const DevCfg* __restrict__ Cp, int B, int n_steps, const double* __restrict__ traj,
+                              double* __restrict__ rpm, double* __restrict__ Tm, double* __restrict__ P,
+                              double* __restrict__ E) {
+    const DevCfg& C = *Cp;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double Ts = C.Tvec[0];
+    double acc = 0.0;
+    const double kr = (30.0 / 3.14159265358979323846);
+    for (int k = 0; k < n_steps; ++k) {
+        const double v = traj[((size_t)k * EEPACC_OUT_N + EEPACC_OUT_V) * B + b];
+        const double x = traj[((size_t)k * EEPACC_OUT_N + EEPACC_OUT_FM) * B + b];
+        const double y = kr * v * C.phi;
+        const double sg = (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0);
+        const double tm = x / C.phi / pow(C.eta_TF, sg);
+        const double* bb = C.b5;
+        const double x2 = x * x, x3 = x2 * x, x4 = x3 * x, x5 = x4 * x;
+        const double y2 = y * y, y3 = y2 * y, y4 = y3 * y, y5 = y4 * y;
+        const double p = bb[0] + bb[1] * x + bb[2] * y + bb[3] * x2 + bb[4] * x * y + bb[5] * y2 + bb[6] * x3 +
+                         bb[7] * x2 * y + bb[8] * x * y2 + bb[9] * y3 + bb[10] * x4 + bb[11] * x3 * y +
+                         bb[12] * x2 * y2 + bb[13] * x * y3 + bb[14] * y4 + bb[15] * x5 + bb[16] * x4 * y +
+                         bb[17] * x3 * y2 + bb[18] * x2 * y3 + bb[19] * x * y4 + bb[20] * y5;
+        acc += p;
+        const size_t o = (size_t)k * B + b;
+        rpm[o] = y; Tm[o] = tm; P[o] = p; E[o] = Ts * acc;
+    }
+}
+
+}  // namespace eepacc
+
+// ----------------------------------------------------------------------------------------------
+// host-side launchers used by eepacc_capi.cpp
+namespace eepacc {
+
+constexpr int kMMax = 48;
+
+size_t ab_smem_bytes(int N) {
+    size_t off = ((size_t)N * N * sizeof(double) + 15) & ~(size_t)15;
+    return off + sizeof(WaveMem<kMMax>) * kWavesPerBlock;
+}
+
+hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const double* v, const double* a_prev,
+                          const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                          unsigned long long* codes, double* out, double* s_pred, double* v_pred,
+                          int32_t* status, int32_t* iters, hipStream_t stream) {
+    const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMax>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                       ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
+                       s_pred, v_pred, status, iters);
+    return hipGetLastError();
+}
+
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int n_steps, const double* s0, const double* v0,
+                            const double* a_m1, const double* s_tv, const double* v_tv, double* traj,
+                            int32_t* status, int32_t* iters_total, hipStream_t stream) {
+    const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMax>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                       ab_smem_bytes(N), stream, dC, B, n_steps, s0, v0, a_m1, s_tv, v_tv, traj, status,
+                       iters_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
+                              double* P, double* E, hipStream_t stream) {
+    hipLaunchKernelGGL(k_postprocess, dim3((B + 127) / 128), dim3(128), 0, stream, dC, B, n_steps, traj, rpm, Tm, P, E);
+    return hipGetLastError();
+}
+
+hipError_t set_max_smem() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ab_step<kMMax>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_run_abmpc<kMMax>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace eepacc

@@ -36,7 +36,7 @@ extern "C" {
 #define EEPACC_EDEVICE      -3   /* HIP runtime error (message: eepacc_last_error())   */
 #define EEPACC_ENOTSUP      -4   /* setting valid in the reference but not built here  */
 
-#define EEPACC_MAX_HORIZON   64  /* N_hor upper limit of the HIP kernels               */
+#define EEPACC_MAX_HORIZON   63  /* N_hor upper limit of the HIP kernels               */
 
 /* Vehicle constants: the struct V returned by SetVehicleParameters()
  * (ABO/Functions/Settings/SetVehicleParameters.m:12-133; ORIG/ holds the BMW i3 values). */
