@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ABMPC N=30 dense-QP MPC steps per second at batch 4096 (BASELINE.json).
+
+One "step" = one receding-horizon step (estimate -> condense -> QP -> allocate -> plant) for all
+4096 synthetic S2 scenarios of a GPU (eepacc_mpc_casadi_matlab_amd/scenarios.py).  The timed
+region runs K consecutive closed-loop steps (after W warm-up steps of the same simulation) with
+all inputs resident in HBM; value = instances * K / time over all ranks.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cpu_baseline(OPT, V, sc, n_inst=2, n_steps=60):
+    """The oracle (literal dense condensing + dense active set) on the host, one thread, on a
+    bounded sample of the same workload."""
+    from oracle import Oracle
+    orc = Oracle(OPT, V)
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n_inst):
+        traj, st, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:n_steps, i].copy(),
+                              sc["v_tv"][:n_steps, i].copy())
+        done += n_steps
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="QP steps/s", cores=1, kind="port",
+                sample="%d S2 instances x %d closed-loop steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
+                       % (n_inst, n_steps, OPT["N_hor"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=30)
+    ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from conftest import make_case
+    from eepacc_mpc_casadi_matlab_amd.engine import Engine
+    from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
+    from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank
+    N, B, K, W = args.horizon, args.batch, args.steps, args.warmup
+    OPT, V, _, _ = make_case("ABO", N)
+    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
+    sc = make_s2(B, W + K, lead["V_TO_2Hz"], first_instance=rank * B)   # shard: rank r owns instances [rB, (r+1)B)
+    eng = Engine(OPT, V, device=dev, max_batch=B)
+    d = torch.device("cuda", dev)
+    s_tv = torch.as_tensor(sc["s_tv"], device=d); v_tv = torch.as_tensor(sc["v_tv"], device=d)
+    s0 = torch.as_tensor(sc["s0"], device=d); v0 = torch.as_tensor(sc["v0"], device=d); am1 = torch.as_tensor(sc["a_minus1"], device=d)
+    chunk = args.chunk if args.chunk > 0 else K
+
+    def run(lo, hi, resume):
+        return eng.run_abmpc(s0, v0, am1, s_tv[lo:hi], v_tv[lo:hi], resume=resume)
+
+    # warm-up: W untimed steps of the simulation (also pages the code object in)
+    if W > 0:
+        run(0, W, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(d)
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    launches = 0
+    bad = torch.zeros((), dtype=torch.int64, device=d)
+    energy = torch.zeros((), dtype=torch.float64, device=d)
+    k = W
+    while k < W + K:
+        hi = min(k + chunk, W + K)
+        traj, status = run(k, hi, resume=(k > 0))
+        launches += 1
+        bad += status.sum()
+        k = hi
+    ev1.record(stream)
+    # KPI reduction (the only collective of the job): bad exits, distance, sum a^2
+    kpi = torch.stack([bad.to(torch.float64), traj[-1, OUT["s"]].sum(), (traj[:, OUT["a"]] ** 2).sum()])
+    if world > 1:
+        dist.all_reduce(kpi, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=d)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    iters = eng.last_iterations(B)
+
+    if rank == 0:
+        total_steps = world * B * K
+        value = total_steps / dt
+        nV, nC = 5 * N, 14 * N + 2
+        bytes_mat = 8 * (nV * nV + nC * nV + 3 * nV + 2 * nC) + 8 * (nV + 1)     # SURVEY 8d, R-materialised
+        bytes_fused = 152                                                          # SURVEY 8d, R-fused (compulsory)
+        launch_s = (kernel_ms / 1e3) / launches
+        qp_per_launch = B * (K / launches)
+        achieved_mat = bytes_mat * qp_per_launch / launch_s / 1e9
+        res = {
+            "metric": "QP steps/sec (whole node), ABMPC N=30 dense QP at batch 4096",
+            "value": value, "unit": "QP steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ABMPC N=%d fp64, batch=%d synthetic S2 ego/lead scenarios per GPU, closed loop" % (N, B),
+                       "batch_per_gpu": B, "horizon": N, "steps_per_launch": int(K / launches),
+                       "parallelism": "instances sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved_mat, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved_mat / 8000.0, "traffic": None,
+                         "definition": "R-materialised (SURVEY.md 8d): bytes the reference's dense-QP API moves per QP step "
+                                       "(%d B at N=%d) x QP steps per launch / mean k_run_abmpc launch time (HIP events); "
+                                       "the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it"
+                                       % (bytes_mat, N, bytes_fused),
+                         "kernel": "k_run_abmpc", "launches": launches, "launch_ms": launch_s * 1e3},
+            "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (K / launches),
+                       "bad_exits": int(kpi[0].item())},
+            "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(OPT, V, sc)
+            res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

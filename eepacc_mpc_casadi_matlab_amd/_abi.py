@@ -9,7 +9,7 @@ import numpy as np
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 
-EEPACC_MAX_HORIZON = 64
+EEPACC_MAX_HORIZON = 63
 
 OUT_FIELDS = ["s", "v", "Fm", "Fb", "a", "xi_v", "xi_h", "xi_s", "xi_f", "cost", "DistHor", "a_qp"]
 OUT_N = len(OUT_FIELDS)

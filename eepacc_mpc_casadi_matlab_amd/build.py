@@ -23,6 +23,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"]
+    cmd += os.environ.get("EEPACC_EXTRA_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB]
     if verbose:

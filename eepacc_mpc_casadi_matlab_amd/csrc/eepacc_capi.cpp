@@ -15,8 +15,9 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream);
-hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int n_steps, const double* s0, const double* v0,
-                            const double* a_m1, const double* s_tv, const double* v_tv, double* traj,
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int k_start, int n_steps, const double* s0,
+                            const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
+                            double* carry, unsigned long long* codes, double* traj,
                             int32_t* status, int32_t* iters_total, hipStream_t stream);
 hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
                               double* P, double* E, hipStream_t stream);
@@ -37,11 +38,16 @@ struct eepacc_handle {
     double* d_Hinv = nullptr;
     unsigned long long* d_codes = nullptr;   // [max_batch][64]
     int32_t* d_iters = nullptr;              // [max_batch]
+    double* d_carry = nullptr;               // [6][B] closed-loop carry (see k_run_abmpc)
     int last_B = 0;
+    int k_done = 0;                          // closed-loop steps already run since the last reset
+    int carry_B = 0;
 };
 
 extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
 extern "C" int eepacc_version(void) { return EEPACC_VERSION; }
+extern "C" int eepacc_sizeof_settings(void) { return (int)sizeof(eepacc_settings); }
+extern "C" int eepacc_sizeof_vehicle(void) { return (int)sizeof(eepacc_vehicle); }
 
 // symmetric positive definite inverse (Gauss-Jordan in long double; N <= 63)
 static bool spd_inverse(std::vector<long double>& A, int n) {
@@ -173,6 +179,8 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMemset(h->d_codes, 0, (size_t)max_batch * 64 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&h->d_iters, (size_t)max_batch * sizeof(int32_t)));
     HIPCHK(hipMemset(h->d_iters, 0, (size_t)max_batch * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_carry, (size_t)max_batch * 6 * sizeof(double)));
+    HIPCHK(hipMemset(h->d_carry, 0, (size_t)max_batch * 6 * sizeof(double)));
     HIPCHK(eepacc::set_max_smem());
     *out = h;
     return EEPACC_OK;
@@ -185,6 +193,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_Hinv) (void)hipFree(h->d_Hinv);
     if (h->d_codes) (void)hipFree(h->d_codes);
     if (h->d_iters) (void)hipFree(h->d_iters);
+    if (h->d_carry) (void)hipFree(h->d_carry);
     delete h;
 }
 
@@ -192,6 +201,7 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     if (!h) return fail(EEPACC_EINVAL, "NULL handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemset(h->d_codes, 0, (size_t)h->max_batch * 64 * sizeof(unsigned long long)));
+    h->k_done = 0; h->carry_B = 0;
     return EEPACC_OK;
 }
 
@@ -219,9 +229,12 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: NULL buffer");
     if (B == 0 || n_steps == 0) return EEPACC_OK;
     HIPCHK(hipSetDevice(h->device));
+    if (h->k_done > 0 && h->carry_B != B)
+        return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");
     h->last_B = B;
-    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status,
-                                    h->d_iters, (hipStream_t)stream));
+    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
+                                    h->d_carry, h->d_codes, traj, status, h->d_iters, (hipStream_t)stream));
+    h->k_done += n_steps; h->carry_B = B;
     return EEPACC_OK;
 }
 
@@ -233,6 +246,7 @@ extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const
     HIPCHK(hipSetDevice(h->device));
     double *d_in = nullptr, *d_tv = nullptr, *d_traj = nullptr;
     int32_t* d_status = nullptr;
+    int rc0 = EEPACC_OK;
     const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
     HIPCHK(hipMalloc(&d_in, 3 * nB * sizeof(double)));
     HIPCHK(hipMalloc(&d_tv, 2 * nT * sizeof(double)));
@@ -243,6 +257,8 @@ extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const
     HIPCHK(hipMemcpy(d_in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    rc0 = eepacc_reset(h);
+    if (rc0 != EEPACC_OK) return rc0;
     int rc = eepacc_run_abmpc(h, B, n_steps, d_in, d_in + nB, d_in + 2 * nB, d_tv, d_tv + nT, d_traj, d_status, nullptr);
     if (rc == EEPACC_OK) {
         HIPCHK(hipDeviceSynchronize());

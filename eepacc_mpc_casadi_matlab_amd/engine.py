@@ -36,6 +36,10 @@ def load_library() -> C.CDLL:
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     lib.eepacc_last_error.restype = C.c_char_p
     lib.eepacc_version.restype = C.c_int
+    lib.eepacc_sizeof_settings.restype = C.c_int
+    lib.eepacc_sizeof_vehicle.restype = C.c_int
+    if lib.eepacc_sizeof_settings() != C.sizeof(SettingsPOD) or lib.eepacc_sizeof_vehicle() != C.sizeof(Vehicle):
+        raise EepaccError("ctypes mirror of include/eepacc.h is out of date (struct size mismatch)")
     lib.eepacc_create.argtypes = [C.POINTER(vp), C.POINTER(SettingsPOD), C.POINTER(Vehicle), C.c_int, C.c_int]
     lib.eepacc_destroy.argtypes = [vp]
     lib.eepacc_destroy.restype = None
@@ -49,7 +53,7 @@ def load_library() -> C.CDLL:
     return lib
 
 
-ABI_SYMBOLS = ["eepacc_last_error", "eepacc_version", "eepacc_create", "eepacc_destroy", "eepacc_reset",
+ABI_SYMBOLS = ["eepacc_last_error", "eepacc_version", "eepacc_sizeof_settings", "eepacc_sizeof_vehicle", "eepacc_create", "eepacc_destroy", "eepacc_reset",
                "eepacc_ab_step", "eepacc_run_abmpc", "eepacc_fb_step", "eepacc_run_fbmpc",
                "eepacc_run_abmpc_host", "eepacc_run_fbmpc_host", "eepacc_postprocess",
                "eepacc_last_iterations"]
@@ -115,9 +119,12 @@ class Engine:
         return out, sp, vp, status
 
     # B1 ------------------------------------------------------------------------------------
-    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv):
-        """s_tv, v_tv: [n_steps, B] lead traces.  Returns traj [n_steps, OUT_N, B], status [n_steps, B]."""
+    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False):
+        """s_tv, v_tv: [n_steps, B] lead traces.  Returns traj [n_steps, OUT_N, B], status [n_steps, B].
+        resume=True continues the simulation of the previous call (s_tv/v_tv hold the next rows)."""
         t = self.torch
+        if not resume:
+            self.reset()
         s_tv = t.as_tensor(s_tv, dtype=t.float64, device=self.device).contiguous()
         v_tv = t.as_tensor(v_tv, dtype=t.float64, device=self.device).contiguous()
         n_steps, B = s_tv.shape

@@ -105,6 +105,8 @@ enum {
 
 const char* eepacc_last_error(void);
 int  eepacc_version(void);
+int  eepacc_sizeof_settings(void);   /* sizeof(eepacc_settings) as compiled: binding self-check */
+int  eepacc_sizeof_vehicle(void);
 
 /* Create / destroy.  Replaces the one-time set-up part of RunOpt_ABMPC / RunOpt_FBMPC
  * (ABO/RunOpt_ABMPC.m:14-123: unpack settings, state-space matrices, conic(...) creation).
@@ -134,7 +136,10 @@ int  eepacc_ab_step(eepacc_handle* h, int B,
  * (ABO/RunOpt_ABMPC.m:154-340 incl. measurement block, plant, force allocation).
  * n_steps = N_sim+1 iterations (kk = 0..N_sim).  Device inputs: s0,v0,a_minus1 [B];
  * s_tv,v_tv [n_steps][B] lead traces (already shifted by TVlength, ABO/Main.m:88).
- * Device outputs: traj [n_steps][EEPACC_OUT_N][B]; status [n_steps][B]. */
+ * Device outputs: traj [n_steps][EEPACC_OUT_N][B]; status [n_steps][B].
+ * The handle carries the loop state: the first call after eepacc_create/eepacc_reset starts
+ * at kk = 0, later calls continue where the previous one stopped (s_tv/v_tv then hold the
+ * rows of the continued steps), so a long simulation can be run in chunks. */
 int  eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps,
                       const double* s0, const double* v0, const double* a_minus1,
                       const double* s_tv, const double* v_tv,

@@ -1,0 +1,173 @@
+"""Parity of the HIP ABMPC path (through the C-ABI) with the CPU oracle and the reference goldens.
+
+Tolerances (fp64, stated per SURVEY.md section 7.1 / BASELINE.md section 3): slacks, speeds,
+accelerations 1e-9 (absolute, SI units); positions 1e-8 m; forces 1e-6 N; QP cost 1e-8 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_case, load_golden, golden_step_inputs
+from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
+from eepacc_mpc_casadi_matlab_amd.scenarios import make_s1, make_s2
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(s=1e-8, v=1e-9, Fm=1e-6, Fb=1e-6, a=1e-9, xi_v=1e-9, xi_h=1e-9, xi_s=1e-9, xi_f=1e-9,
+           DistHor=1e-8, a_qp=1e-9)
+
+
+def _engine(OPT, V, max_batch=4096):
+    from eepacc_mpc_casadi_matlab_amd.engine import Engine
+    return Engine(OPT, V, device=0, max_batch=max_batch)
+
+
+def _cols(inps):
+    return {n: np.array([d[n] for d in inps]) for n in ("s", "v", "a_prev", "t0", "s_tv", "v_tv", "a_tv_prev")}
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("tree", ["ABO", "ORIG"])
+def test_open_loop_all_golden_steps(tree, torch_mod):
+    """Every one of the 871 saved MPC steps as an independent cold-started QP."""
+    OPT, V, s_tv, v_tv = make_case(tree, 20)
+    G = load_golden(f"{tree.lower()}_abmpc")
+    eng = _engine(OPT, V)
+    c = _cols([golden_step_inputs(G, s_tv, v_tv, k) for k in range(871)])
+    out, sp, vp, status = eng.ab_step(**c)
+    o = out.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    for n in ("xi_v", "xi_h", "xi_s", "xi_f", "Fm", "Fb", "a", "DistHor"):
+        g = G[n if n == "DistHor" else n + "_opt"]
+        assert np.abs(o[OUT[n]] - g).max() < TOL[n], n
+    np.testing.assert_array_equal(o[OUT["s"]], G["s_opt"])
+
+
+@pytest.mark.parametrize("tree", ["ABO", "ORIG"])
+def test_closed_loop_golden_trajectory(tree, torch_mod):
+    OPT, V, s_tv, v_tv = make_case(tree, 20)
+    G = load_golden(f"{tree.lower()}_abmpc")
+    eng = _engine(OPT, V, 8)
+    B = 5                                   # odd: exercises a partially filled block
+    stv = np.repeat(s_tv[:871, None], B, 1); vtv = np.repeat(v_tv[:871, None], B, 1)
+    traj, status = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv, vtv)
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    for n in ("s", "v", "xi_v", "xi_h", "xi_s", "xi_f", "Fm", "Fb", "a", "DistHor"):
+        g = G[n if n == "DistHor" else n + "_opt"]
+        assert np.abs(tr[:, OUT[n], 0] - g).max() < TOL[n], n
+    assert np.abs(tr - tr[:, :, :1]).max() == 0.0          # identical instances, identical results
+    rpm, Tm, P, E = [x.cpu().numpy()[:, 0] for x in eng.postprocess(traj)]
+    for a, b in ((rpm, "rpm_opt"), (Tm, "Tm_opt"), (P, "P_opt"), (E, "E_opt")):
+        assert (np.abs(a - G[b]) / np.maximum(1.0, np.abs(G[b]))).max() < 1e-9, b
+    # chunked run (resume) is bit-identical to the single launch
+    t1, s1 = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv[:300], vtv[:300])
+    t2, s2 = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv[300:], vtv[300:], resume=True)
+    both = np.concatenate([t1.cpu().numpy(), t2.cpu().numpy()], 0)
+    assert np.array_equal(both, tr)
+
+
+@pytest.mark.parametrize("tree,N,B", [("ABO", 20, 192), ("ABO", 30, 96), ("ORIG", 30, 48)])
+def test_open_loop_seeded_batch_vs_oracle(tree, N, B, torch_mod):
+    """S1 inputs (perturbed golden states): every output incl. predicted trajectories and cost."""
+    from oracle import Oracle
+    OPT, V, s_tv, v_tv = make_case(tree, N)
+    G = load_golden(f"{tree.lower()}_abmpc")
+    s1 = make_s1(B, G, s_tv, v_tv)
+    eng = _engine(OPT, V)
+    args = {k: s1[k] for k in ("s", "v", "a_prev", "t0", "s_tv", "v_tv", "a_tv_prev")}
+    out, sp, vp, status = eng.ab_step(**args)
+    o = out.cpu().numpy(); sp = sp.cpu().numpy(); vp = vp.cpu().numpy(); st = status.cpu().numpy()
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        r = orc.ab_step(**{k: float(v[i]) for k, v in args.items()})
+        assert r["status"] == st[i] == 0, i
+        for n, t in TOL.items():
+            assert abs(o[OUT[n], i] - r["out"][OUT[n]]) < t, (i, n)
+        assert abs(o[OUT["cost"], i] - r["out"][OUT["cost"]]) < 1e-8 * (1 + abs(r["out"][OUT["cost"]])), i
+        assert np.abs(sp[:, i] - r["s_pred"]).max() < 1e-8
+        assert np.abs(vp[:, i] - r["v_pred"]).max() < 1e-9
+
+
+def test_closed_loop_s2_vs_oracle(torch_mod, lead_trace):
+    """N=30 closed loop on synthetic S2 scenarios against the oracle's closed loop."""
+    from oracle import Oracle
+    OPT, V, _, _ = make_case("ABO", 30)
+    B, n_steps = 6, 120
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"])
+    eng = _engine(OPT, V, 8)
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        ref, st, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        assert st.sum() == 0
+        for n in ("s", "v", "Fm", "Fb", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
+            assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (i, n)
+
+
+def test_full_size_batch_properties(torch_mod, lead_trace):
+    """BASELINE config 2 size (N=30, batch 4096): size-independent properties."""
+    torch = torch_mod
+    OPT, V, _, _ = make_case("ABO", 30)
+    B, n_steps = 4096, 40
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"])
+    eng = _engine(OPT, V, B)
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy(); st = status.cpu().numpy()
+    assert st.sum() == 0
+    assert np.isfinite(tr).all()
+    # (1) determinism
+    traj2, _ = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    assert np.array_equal(traj2.cpu().numpy(), tr)
+    # (2) instances are independent: a permuted batch gives the permuted result
+    perm = np.random.default_rng(0).permutation(B)
+    trp, _ = eng.run_abmpc(sc["s0"][perm], sc["v0"][perm], sc["a_minus1"][perm],
+                           np.ascontiguousarray(sc["s_tv"][:, perm]), np.ascontiguousarray(sc["v_tv"][:, perm]))
+    assert np.array_equal(trp.cpu().numpy(), tr[:, :, perm])
+    # (3) constraints the QP enforces hold on the applied trajectory: slacks >= 0, v >= 0
+    for n in ("xi_v", "xi_h", "xi_s", "xi_f"):
+        assert tr[:, OUT[n]].min() > -1e-9
+    assert tr[:, OUT["v"]].min() > -1e-9
+    # (4) the per-step operator reproduces step k of the closed loop from its inputs
+    k = 17
+    Ts = 0.5
+    s, v = tr[k, OUT["s"]], tr[k, OUT["v"]]
+    a_prev = (v - tr[k - 1, OUT["v"]]) / Ts
+    vtv = sc["v_tv"][k]; vtvp = sc["v_tv"][k - 1]
+    eng.reset()
+    out, _, _, st1 = eng.ab_step(s, v, a_prev, np.full(B, k * Ts), sc["s_tv"][k], vtv, (vtv - vtvp) / Ts)
+    o = out.cpu().numpy()
+    assert st1.cpu().numpy().sum() == 0
+    for n in ("Fm", "Fb", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
+        assert np.abs(o[OUT[n]] - tr[k, OUT[n]]).max() < 10 * TOL[n], n
+
+
+def test_edge_cases(torch_mod, lead_trace):
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    eng = _engine(OPT, V, 16)
+    # B = 1, one step, standstill behind a standing lead: nothing to do but wait
+    out, sp, vp, st = eng.ab_step([0.0], [0.0], [0.0], [0.0], [6.0], [0.0], [0.0])
+    o = out.cpu().numpy()[:, 0]
+    assert st.cpu().numpy()[0] == 0
+    assert abs(o[OUT["xi_v"]] - 60 / 3.6) < 1e-9
+    # lead far away (no headway rows active) and lead closer than the minimum gap (safety slack)
+    out, _, _, st = eng.ab_step([0.0, 0.0], [10.0, 10.0], [0.0, 0.0], [0.0, 0.0], [1e4, 1.0], [10.0, 0.0], [0.0, 0.0])
+    o = out.cpu().numpy()
+    assert st.cpu().numpy().sum() == 0
+    assert o[OUT["xi_h"], 0] == 0.0 and o[OUT["xi_s"], 0] == 0.0
+    assert o[OUT["xi_s"], 1] > 0.0 and o[OUT["xi_h"], 1] > 0.0
+    # infeasible hard row (v0 above v_max): status 1, outputs still finite (reference applies the iterate)
+    out, _, _, st = eng.ab_step([0.0], [60.0], [0.0], [0.0], [1e4], [10.0], [0.0])
+    assert st.cpu().numpy()[0] == 1 and np.isfinite(out.cpu().numpy()).all()
+    # zero-length calls are no-ops
+    import torch
+    e = torch.empty(0, dtype=torch.float64, device="cuda")
+    eng.run_abmpc(e, e, e, torch.empty((3, 0), dtype=torch.float64, device="cuda"),
+                  torch.empty((3, 0), dtype=torch.float64, device="cuda"))

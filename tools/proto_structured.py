@@ -209,6 +209,7 @@ class StructuredQP:
         self.gstate = {g: dict(P=False, pivot=None, compl=False) for g in prob.groups}
         self.iters = 0
         self.events = 0
+        self.refine_rounds = 2
 
     # effective (a-space) normal / rhs / compliance of a working-set row
     def eff(self, j):
@@ -244,6 +245,19 @@ class StructuredQP:
         self.D = np.array([e[2] for e in E])
         S = self.C @ self.Hinv @ self.C.T + np.diag(self.D)
         self.Pm = np.linalg.inv(S)
+
+    def refine(self, extra=None, rounds=2):
+        """iterative refinement of the multipliers against the exactly evaluated residual of the
+        working-set equations C a - D lam = d (the kernel does the same after every solve)"""
+        if not len(self.W):
+            return
+        for _ in range(rounds):
+            a = self.primal(extra)
+            lam = np.array([self.lam[j] for j in self.W])
+            res = self.C @ a - self.D * lam - self.d
+            dl = self.Pm @ res
+            for j, x in zip(self.W, dl):
+                self.lam[j] += x
 
     def primal(self, extra=None):
         """a from the multipliers (extra = (normal, multiplier) of the incoming constraint)."""
@@ -336,6 +350,12 @@ class StructuredQP:
         self.status = 0
         self.factor()
         while True:
+            if len(self.W):
+                lam = -self.Pm @ (self.d + self.C @ (self.Hinv @ self.g_eff()))
+                for j, l in zip(self.W, lam):
+                    self.lam[j] = l
+                if self.refine_rounds:
+                    self.refine(None, self.refine_rounds)
             a = self.primal()
             q = self.most_violated(a)
             if q is None:
@@ -350,6 +370,12 @@ class StructuredQP:
                 if self.events > 20 * max_iter:
                     self.status = 2; done = True; break
                 c, dq, Dq = self.incoming_eff(q)
+                if len(self.W):
+                    lam = -self.Pm @ (self.d + self.C @ (self.Hinv @ (self.g_eff() + lam_q * c)))
+                    for j, l in zip(self.W, lam):
+                        self.lam[j] = l
+                    if self.refine_rounds:
+                        self.refine((c, lam_q), self.refine_rounds)
                 a = self.primal((c, lam_q))
                 viol = c @ a - Dq * lam_q - dq
                 u = self.Hinv @ c
