@@ -26,54 +26,70 @@ constexpr double kTolDual = 1e-12;
 // wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, 64); }
-__device__ __forceinline__ int bcasti(int x, int src) { return __shfl(x, src, 64); }
+// broadcast from a wave-uniform source lane (v_readlane)
+__device__ __forceinline__ double bcast(double x, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), s);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), s);
+    return __hiloint2double(hi, lo);
+}
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+// DPP cross-lane moves (VALU data path, no LDS round trip).  ctrl: row_shr:n = 0x110+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shr:1 = 0x138 (gfx9-family encodings).
+// dpp_zero: lanes without a valid source (or masked rows) read 0; dpp_keep: they keep their value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_zero(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_keep(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane63(double x) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes (Hillis-Steele inside 16-lane rows, then row broadcasts)
+__device__ __forceinline__ double scan_incl(double x) {
+    x += dpp_zero<0x111, 0xf>(x);
+    x += dpp_zero<0x112, 0xf>(x);
+    x += dpp_zero<0x114, 0xf>(x);
+    x += dpp_zero<0x118, 0xf>(x);
+    x += dpp_zero<0x142, 0xa>(x);
+    x += dpp_zero<0x143, 0xc>(x);
     return x;
 }
+__device__ __forceinline__ double wave_sum(double x) { return read_lane63(scan_incl(x)); }
 // exclusive prefix sum over lanes
-__device__ __forceinline__ double scan_excl(double x) {
-    const int l = lane_id();
-    double y = __shfl_up(x, 1, 64);
-    if (l == 0) y = 0.0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_up(y, o, 64);
-        if (l >= o) y += t;
-    }
-    return y;
+__device__ __forceinline__ double scan_excl(double x) { return dpp_zero<0x138, 0xf>(scan_incl(x)); }
+__device__ __forceinline__ double wave_max(double x) {
+    x = fmax(x, dpp_keep<0x111, 0xf>(x));
+    x = fmax(x, dpp_keep<0x112, 0xf>(x));
+    x = fmax(x, dpp_keep<0x114, 0xf>(x));
+    x = fmax(x, dpp_keep<0x118, 0xf>(x));
+    x = fmax(x, dpp_keep<0x142, 0xa>(x));
+    x = fmax(x, dpp_keep<0x143, 0xc>(x));
+    return read_lane63(x);
 }
-// exclusive suffix sum over lanes (sum over lanes > me)
-__device__ __forceinline__ double suffix_excl(double x) {
-    const int l = lane_id();
-    double y = __shfl_down(x, 1, 64);
-    if (l == 63) y = 0.0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_down(y, o, 64);
-        if (l + o < 64) y += t;
-    }
-    return y;
-}
-// arg-min / arg-max with integer payload (ties: smallest payload, deterministic)
-__device__ __forceinline__ void wave_argmin(double& v, int& p) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_xor(v, o, 64);
-        int op = __shfl_xor(p, o, 64);
-        if (ov < v || (ov == v && op < p)) { v = ov; p = op; }
-    }
-}
+// arg-min / arg-max with integer payload; ties go to the lowest lane (deterministic)
 __device__ __forceinline__ void wave_argmax(double& v, int& p) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_xor(v, o, 64);
-        int op = __shfl_xor(p, o, 64);
-        if (ov > v || (ov == v && op < p)) { v = ov; p = op; }
-    }
+    const double best = wave_max(v);
+    const unsigned long long mask = __ballot(v == best);
+    const int src = mask ? (__ffsll((long long)mask) - 1) : 0;
+    p = __builtin_amdgcn_readlane(p, src);
+    v = best;
+}
+__device__ __forceinline__ void wave_argmin(double& v, int& p) {
+    double nv = -v;
+    wave_argmax(nv, p);
+    v = -nv;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -106,7 +122,7 @@ struct WaveMem {                 // one per wave, in LDS
     double P[MMAX * (MMAX + 1) / 2];
     double yv[64], ub[64], av[64];
     double sub[65], vub[65], shv[65], vhv[65];
-    double ws[65], wv[65], wa[65];
+    double ws[65], wv[65], wa[65 + 3 * 65];   // wa[65..] scratch of adjoint()
     double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX], e_D[MMAX];
     double lam[MMAX], sv[MMAX], rv[MMAX], colk[MMAX];
     int w_k[MMAX];
@@ -118,6 +134,7 @@ __device__ __forceinline__ int pidx(int i, int j) { return i >= j ? i * (i + 1) 
 struct Lane {
     int lane, N;
     double T, tau, tau1;          // T_k, tau_k, tau_{k+1}
+    double tau_rev;               // tau_{N-lane} (reversed stage order, see adjoint())
     double ba[kNumRowTypes];      // a-space right-hand sides
     unsigned valid;               // bit t: row (t, lane) exists with a non-zero normal
     double lbF, lbS, lbV, lbH;    // slack lower bounds (constant rows of stage 0 fold in here)
@@ -172,10 +189,27 @@ __device__ __forceinline__ void hom_traj(const Lane& L, double x, double& sh, do
 
 // out_k = sum_i Hinv[i][k] * yv[i]   (Hinv symmetric, table in LDS, yv in LDS)
 __device__ __forceinline__ double hinv_mul(const double* __restrict__ Hs, const double* yv, int N, int lane) {
-    double acc = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const int k = lane < N ? lane : 0;
-    for (int i = 0; i < N; ++i) acc = fma(Hs[i * N + k], yv[i], acc);
-    return lane < N ? acc : 0.0;
+    int i = 0;
+    for (; i + 4 <= N; i += 4) {
+        const double h0 = Hs[(i + 0) * N + k], h1 = Hs[(i + 1) * N + k], h2 = Hs[(i + 2) * N + k], h3 = Hs[(i + 3) * N + k];
+        const double y0 = yv[i], y1 = yv[i + 1], y2 = yv[i + 2], y3 = yv[i + 3];
+        a0 = fma(h0, y0, a0); a1 = fma(h1, y1, a1); a2 = fma(h2, y2, a2); a3 = fma(h3, y3, a3);
+    }
+    for (; i < N; ++i) a0 = fma(Hs[i * N + k], yv[i], a0);
+    return lane < N ? (a0 + a1) + (a2 + a3) : 0.0;
+}
+
+// u = Hinv c for a structured row c = al*Ss[kq]' + be*Sv[kq]' + ga*e_kq + de*e_{kq-1}: a combination of
+// columns of the precomputed tables Hinv*Ss', Hinv*Sv' ([k][j], k = 0..N) and of Hinv itself (LDS)
+__device__ __forceinline__ double hinv_row(const double* Hs, const double* HSs, const double* HSv, int N, int lane,
+                                           int kq, double al, double be, double ga, double de) {
+    if (lane >= N) return 0.0;
+    double u = al * HSs[kq * N + lane] + be * HSv[kq * N + lane];
+    if (kq < N && ga != 0.0) u += ga * Hs[kq * N + lane];
+    if (kq > 0 && de != 0.0) u += de * Hs[(kq - 1) * N + lane];
+    return u;
 }
 
 // a-space normal of the row (kq; al,be,ga,de) evaluated at this lane j:
@@ -192,15 +226,22 @@ __device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, do
 
 // adjoint of the condensing: given stage weights on (s_k, v_k, a_k) in LDS (ws, wv, wa, k = 0..N)
 // returns d/da_j of sum_k ws_k s_k + wv_k v_k + wa_k a_k  for lane j < N
-__device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, const double* wa) {
+__device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, double* wa) {
+    // suffix sums over stages k > j are prefix sums over the reversed stage order: lane r holds
+    // stage N - r; the three running sums are written back in stage order through LDS (wa[65..])
+    const int r = L.lane, N = L.N;
+    const int k = N - r;
+    const bool in = k >= 0;
+    const double s = in ? ws[k] : 0.0, v = in ? wv[k] : 0.0;
+    const double tk = in ? L.tau_rev : 0.0;
+    const double WS = scan_excl(s), WV = scan_excl(v), WST = scan_excl(s * tk);
+    double* tmp = wa + 65;
+    if (in) { tmp[k] = WS; tmp[65 + k] = WV; tmp[130 + k] = WST; }
+    WSYNC();
     const int j = L.lane;
-    const bool in = j <= L.N;
-    double s = in ? ws[j] : 0.0, v = in ? wv[j] : 0.0;
-    double WS = suffix_excl(s);
-    double WV = suffix_excl(v);
-    double WST = suffix_excl(s * L.tau);
     double g = 0.0;
-    if (j < L.N) g = wa[j] + L.T * (WV + WST - (L.tau1 - 0.5 * L.T) * WS);
+    if (j < N) g = wa[j] + L.T * (tmp[65 + j] + tmp[130 + j] - (L.tau1 - 0.5 * L.T) * tmp[j]);
+    WSYNC();
     return g;
 }
 
@@ -257,13 +298,11 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     WSYNC();
     if (m == 0) return 0;
     // S columns
+    const double* HSs = Hs + N * N;
+    const double* HSv = HSs + (N + 1) * N;
     for (int j = 0; j < m; ++j) {
         const int kj = M.w_k[j];
-        const double al = M.e_al[j], be = M.e_be[j], ga = M.e_ga[j], de = M.e_de[j];
-        double cj = normal_at(L, kj, al, be, ga, de, tauv[kj]);
-        if (lane < N) M.yv[lane] = cj;
-        WSYNC();
-        double u = hinv_mul(Hs, M.yv, N, lane);
+        double u = hinv_row(Hs, HSs, HSv, N, lane, kj, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j]);
         double su, vu;
         hom_traj(L, u, su, vu);
         if (lane < N) M.ub[lane] = u;
@@ -271,11 +310,11 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
         WSYNC();
         if (lane >= j && lane < m) {
             const int ki = M.w_k[lane];
-            double s = M.e_al[lane] * M.sub[ki] + M.e_be[lane] * M.vub[ki];
-            if (ki < N) s += M.e_ga[lane] * M.ub[ki];
-            if (ki > 0 && ki <= N) s += M.e_de[lane] * M.ub[ki - 1];
-            if (lane == j) s += M.e_D[lane];
-            M.P[pidx(lane, j)] = s;
+            double sx = M.e_al[lane] * M.sub[ki] + M.e_be[lane] * M.vub[ki];
+            if (ki < N) sx += M.e_ga[lane] * M.ub[ki];
+            if (ki > 0 && ki <= N) sx += M.e_de[lane] * M.ub[ki - 1];
+            if (lane == j) sx += M.e_D[lane];
+            M.P[pidx(lane, j)] = sx;
         }
         WSYNC();
     }
@@ -293,21 +332,36 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
         const double inv = 1.0 / d;
         if (lane < m) M.colk[lane] = M.P[pidx(lane, k)];
         WSYNC();
-        for (int r = 0; r < m; ++r) {
-            if (lane <= r) {
-                double v;
-                if (r == k && lane == k) v = -inv;
-                else if (r == k) v = M.colk[lane] * inv;          // (k, lane), lane < k
-                else if (lane == k) v = M.colk[r] * inv;          // (r, k), r > k
-                else v = M.P[pidx(r, lane)] - M.colk[r] * M.colk[lane] * inv;
-                M.P[pidx(r, lane)] = v;
+        if (lane < m) {
+            // lane owns column `lane` of the lower triangle: rows r = lane .. m-1 (independent updates)
+            const double cl = M.colk[lane] * inv;
+            int r = lane;
+            for (; r + 4 <= m; r += 4) {
+                const int i0 = pidx(r, lane), i1 = pidx(r + 1, lane), i2 = pidx(r + 2, lane), i3 = pidx(r + 3, lane);
+                const double p0 = M.P[i0], p1 = M.P[i1], p2 = M.P[i2], p3 = M.P[i3];
+                const double c0 = M.colk[r], c1 = M.colk[r + 1], c2 = M.colk[r + 2], c3 = M.colk[r + 3];
+                double v0 = p0 - c0 * cl, v1 = p1 - c1 * cl, v2 = p2 - c2 * cl, v3 = p3 - c3 * cl;
+                if (lane == k) { v0 = c0 * inv; v1 = c1 * inv; v2 = c2 * inv; v3 = c3 * inv; }
+                if (r == k) v0 = (lane == k) ? -inv : cl;
+                if (r + 1 == k) v1 = cl;
+                if (r + 2 == k) v2 = cl;
+                if (r + 3 == k) v3 = cl;
+                M.P[i0] = v0; M.P[i1] = v1; M.P[i2] = v2; M.P[i3] = v3;
+            }
+            for (; r < m; ++r) {
+                const int i0 = pidx(r, lane);
+                const double c0 = M.colk[r];
+                double v0 = M.P[i0] - c0 * cl;
+                if (lane == k) v0 = c0 * inv;
+                if (r == k) v0 = (lane == k) ? -inv : cl;
+                M.P[i0] = v0;
             }
         }
         WSYNC();
     }
     if (singular) return -1;
-    for (int r = 0; r < m; ++r)
-        if (lane <= r) M.P[pidx(r, lane)] = -M.P[pidx(r, lane)];
+    if (lane < m)
+        for (int r = lane; r < m; ++r) M.P[pidx(r, lane)] = -M.P[pidx(r, lane)];
     WSYNC();
     return m;
 }
@@ -404,8 +458,7 @@ __device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, W
     WSYNC();
     L.a = -hinv_mul(Hs, M.yv, L.N, L.lane);
     hom_traj(L, L.a, L.sh, L.vh);
-    L.am1 = __shfl_up(L.a, 1, 64);
-    if (L.lane == 0) L.am1 = 0.0;
+    L.am1 = dpp_zero<0x138, 0xf>(L.a);
     if (L.lane < L.N) M.av[L.lane] = L.a;
     if (L.lane <= L.N) { M.shv[L.lane] = L.sh; M.vhv[L.lane] = L.vh; }
     WSYNC();
@@ -622,10 +675,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             if (kq < N) viol += qga * M.av[kq];
             if (kq > 0) viol += qde * M.av[kq - 1];
             // u = Hinv c_q and its trajectories
-            double cj = normal_at(L, kq, qal, qbe, qga, qde, tauv[kq]);
-            if (lane < N) M.yv[lane] = cj;
-            WSYNC();
-            double u = hinv_mul(Hs, M.yv, N, lane);
+            double u = hinv_row(Hs, Hs + N * N, Hs + N * N + (N + 1) * N, N, lane, kq, qal, qbe, qga, qde);
             double su, vu;
             hom_traj(L, u, su, vu);
             if (lane < N) M.ub[lane] = u;
@@ -917,6 +967,7 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const
     L.T = lane < N ? C.Tvec[lane] : 0.0;
     L.tau = C.tau[kk];
     L.tau1 = C.tau[kk + (lane < N ? 1 : 0)];
+    L.tau_rev = C.tau[lane <= N ? N - lane : 0];
     Cfg c;
     c.N = N; c.tau_min = C.tau_min; c.wF = C.w_f; c.wS = C.w_s; c.wV = C.w_v; c.wH = 100.0 * C.w_h; c.qH = 2.0 * C.w_h;
     // estimators (A2)
@@ -1034,17 +1085,20 @@ __device__ __forceinline__ unsigned long long shift_codes(unsigned long long cod
 
 constexpr int kWavesPerBlock = 2;
 
+// LDS layout of a block: [Hinv N x N][HSs (N+1) x N][HSv (N+1) x N] shared, then one WaveMem per wave
+__host__ __device__ inline size_t table_doubles(int N) { return (size_t)N * N + 2 * (size_t)(N + 1) * N; }
+
 template <int MMAX>
 __device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, const double*& Hs) {
     Hs = reinterpret_cast<const double*>(smem);
-    size_t off = ((size_t)N * N * sizeof(double) + 15) & ~(size_t)15;
+    size_t off = (table_doubles(N) * sizeof(double) + 15) & ~(size_t)15;
     return reinterpret_cast<WaveMem<MMAX>*>(smem + off) + (threadIdx.x >> 6);
 }
 
 __device__ __forceinline__ void load_hinv(unsigned char* smem, const DevCfg& C) {
     double* Hs = reinterpret_cast<double*>(smem);
-    const int n2 = C.N * C.N;
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) Hs[i] = C.Hinv[i];
+    const int n = (int)table_doubles(C.N);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) Hs[i] = C.Hinv[i];
     __syncthreads();
 }
 
@@ -1191,7 +1245,7 @@ namespace eepacc {
 constexpr int kMMax = 64;
 
 size_t ab_smem_bytes(int N) {
-    size_t off = ((size_t)N * N * sizeof(double) + 15) & ~(size_t)15;
+    size_t off = (table_doubles(N) * sizeof(double) + 15) & ~(size_t)15;
     return off + sizeof(WaveMem<kMMax>) * kWavesPerBlock;
 }
 

@@ -84,12 +84,18 @@ def test_open_loop_seeded_batch_vs_oracle(tree, N, B, torch_mod):
     out, sp, vp, status = eng.ab_step(**args)
     o = out.cpu().numpy(); sp = sp.cpu().numpy(); vp = vp.cpu().numpy(); st = status.cpu().numpy()
     orc = Oracle(OPT, V)
+    # the ORIG weights reach 1e7 (ORIG/Settings.m:48-62): its QPs are ~1e4 times worse conditioned,
+    # forces are compared to 1e-5 N there (relative 1e-8 of the force range)
+    tol = dict(TOL)
+    if tree == "ORIG":
+        tol.update(Fm=1e-5, Fb=1e-5)
     for i in range(B):
         r = orc.ab_step(**{k: float(v[i]) for k, v in args.items()})
         assert r["status"] == st[i] == 0, i
-        for n, t in TOL.items():
+        for n, t in tol.items():
             assert abs(o[OUT[n], i] - r["out"][OUT[n]]) < t, (i, n)
-        assert abs(o[OUT["cost"], i] - r["out"][OUT["cost"]]) < 1e-8 * (1 + abs(r["out"][OUT["cost"]])), i
+        ctol = 1e-6 if tree == "ORIG" else 1e-8
+        assert abs(o[OUT["cost"], i] - r["out"][OUT["cost"]]) < ctol * (1 + abs(r["out"][OUT["cost"]])), i
         assert np.abs(sp[:, i] - r["s_pred"]).max() < 1e-8
         assert np.abs(vp[:, i] - r["v_pred"]).max() < 1e-9
 
