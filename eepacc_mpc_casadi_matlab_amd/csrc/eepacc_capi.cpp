@@ -235,9 +235,9 @@ extern "C" int eepacc_ab_step(eepacc_handle* h, int B, const double* s, const do
                               double* out, double* s_pred, double* v_pred, int32_t* status, void* stream) {
     if (!h) return fail(EEPACC_EINVAL, "NULL handle");
     if (B < 0 || B > h->max_batch) return fail(EEPACC_EINVAL, "B exceeds max_batch of the handle");
+    if (B == 0) return EEPACC_OK;
     if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out || !status)
         return fail(EEPACC_EINVAL, "eepacc_ab_step: NULL buffer");
-    if (B == 0) return EEPACC_OK;
     HIPCHK(hipSetDevice(h->device));
     h->last_B = B;
     HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
@@ -250,9 +250,9 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
                                 int32_t* status, void* stream) {
     if (!h) return fail(EEPACC_EINVAL, "NULL handle");
     if (B < 0 || B > h->max_batch || n_steps < 0) return fail(EEPACC_EINVAL, "bad B / n_steps");
+    if (B == 0 || n_steps == 0) return EEPACC_OK;
     if (!s0 || !v0 || !a_minus1 || !s_tv || !v_tv || !traj || !status)
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: NULL buffer");
-    if (B == 0 || n_steps == 0) return EEPACC_OK;
     HIPCHK(hipSetDevice(h->device));
     if (h->k_done > 0 && h->carry_B != B)
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");

@@ -21,6 +21,7 @@ namespace eepacc {
 constexpr double kInf = 1e300;
 constexpr double kTolViol = 1e-11;
 constexpr double kTolDual = 1e-12;
+constexpr int kSinglePasses = 8;
 
 // ----------------------------------------------------------------------------------------------
 // wave primitives
@@ -137,6 +138,7 @@ struct Lane {
     double tau_rev;               // tau_{N-lane} (reversed stage order, see adjoint())
     double ba[kNumRowTypes];      // a-space right-hand sides
     unsigned valid;               // bit t: row (t, lane) exists with a non-zero normal
+    unsigned ign;                 // bit t / 16+g: duplicate row ignored during this solve
     double lbF, lbS, lbV, lbH;    // slack lower bounds (constant rows of stage 0 fold in here)
     unsigned long long code;      // 4 bits per type: 0 off, 1 in working set, 2 group pivot, 3 compliant
     double chw;                   // headway-policy coefficient T_hwp + G_hwp*v_est(k)
@@ -245,7 +247,7 @@ __device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const
     return g;
 }
 
-enum Ev : int { EV_NONE = 0, EV_DROP, EV_COMPL, EV_RIGID, EV_CAP, EV_CAPIN };
+enum Ev : int { EV_NONE = 0, EV_DROP, EV_COMPL, EV_DROPH, EV_CAP, EV_CAPIN };
 
 struct SolveStats { int status, iters, events, m; };
 
@@ -320,15 +322,11 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     }
     // in-place inversion by symmetric sweeps: after sweeping every pivot P = -S^-1
     int singular = 0;
-    double scale = 0.0;
-    if (lane < m) scale = fabs(M.P[pidx(lane, lane)]);
-    {
-        int dummy = lane;
-        wave_argmax(scale, dummy);
-    }
+    if (lane < m) M.sv[lane] = fabs(M.P[pidx(lane, lane)]);     // original diagonal (pivot scale)
+    WSYNC();
     for (int k = 0; k < m; ++k) {
         const double d = M.P[pidx(k, k)];
-        if (!(d > 1e-13 * scale)) { singular = 1; break; }
+        if (!(d > 1e-12 * M.sv[k])) { singular = 1; break; }
         const double inv = 1.0 / d;
         if (lane < m) M.colk[lane] = M.P[pidx(lane, k)];
         WSYNC();
@@ -517,7 +515,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
     // ---- warm start: make the shifted working set dual feasible -------------------------
     {
         bool ok = false;
-        for (int pass = 0; pass < 6 && !ok; ++pass) {
+        for (int pass = 0; pass < kSinglePasses + 6 && !ok; ++pass) {
             m = rebuild_and_factor(L, c, M, Hs, tauv);
             if (m < 0) break;
             if (m == 0) { ok = true; break; }
@@ -533,9 +531,17 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             WSYNC();
             solve_multipliers(M, m, lane, N);
             scatter_to_types<MMAX>(L, M.lam, L.lamt);
-            // repair
+            // repair of dual infeasibilities.  The first passes fix only the worst one (a single
+            // wrong row usually drags many multipliers negative; dropping them all would throw the
+            // warm start away), later passes fix all of them at once.
+            const bool single = pass < kSinglePasses;
+            double lmax = 0.0;
+            if (lane < m) lmax = fabs(M.lam[lane]);
+            lmax = wave_max(lmax);
+            const double tol = kTolDual * (1.0 + lmax);
             int changed = 0;
             double sumF = 0.0, sumS = 0.0, sumV = 0.0;
+            double worst = tol; int fix = 0x7fffffff;
 #pragma unroll
             for (int t = 0; t < kNumRowTypes; ++t) {
                 int cd = code_of(L, t);
@@ -543,35 +549,64 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 int g2 = lane_group(L, t);
                 double l = L.lamt[t];
                 if (g2 == G_H) {
-                    if (cd == 3) { if (l < c.wH - kTolDual) { set_code(L, t, 1); changed = 1; } }
-                    else if (l < -kTolDual) { set_code(L, t, 0); changed = 1; }
-                    else if (l > c.wH + kTolDual) { set_code(L, t, 3); changed = 1; }
+                    if (cd == 3) {
+                        // xi_h < 0 (multiplier below w) is a primal infeasibility the main loop repairs
+                        if (-l > tol) { if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; } }
+                    } else if (-l > tol) {
+                        if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
+                    } else if (l - c.wH > tol) {
+                        if (!single) { set_code(L, t, 3); changed = 1; } else if (l - c.wH > worst) { worst = l - c.wH; fix = (EV_COMPL << 16) | (lane << 5) | t; }
+                    }
                 } else {
-                    if (l < -kTolDual) { set_code(L, t, 0); changed = 1; l = 0.0; }
+                    if (-l > tol) {
+                        if (!single) { set_code(L, t, 0); changed = 1; l = 0.0; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
+                    }
                     if (g2 == G_F) sumF += l; else if (g2 == G_S) sumS += l; else if (g2 == G_V) sumV += l;
                 }
             }
-            int any = __any(changed);
-            if (!any) {
-                // group margins (bound multiplier in Z, pivot multiplier in P)
+            // group margins (bound multiplier in Z, pivot multiplier in P)
+            if (lane < N) {
 #pragma unroll
                 for (int g2 = G_F; g2 <= G_V; ++g2) {
                     double sum = g2 == G_F ? sumF : (g2 == G_S ? sumS : sumV);
                     double w = group_w(c, g2);
-                    if (lane < N && w - sum < -kTolDual * (1.0 + w)) {
-                        changed = 1;
-                        int p = pivot_of(L, g2);
-                        if (p >= 0) set_code(L, p, 0);
-                        int best = -1; double bl = -1.0;
+                    double viol = sum - w;
+                    if (viol > tol * (1.0 + w)) {
+                        if (single) { if (viol > worst) { worst = viol; fix = (EV_CAP << 16) | (lane << 5) | g2; } }
+                        else if (!changed) {
+                            changed = 1;
+                            int p = pivot_of(L, g2);
+                            if (p >= 0) set_code(L, p, 0);
+                            int bestt = -1; double bl = -1e300;
 #pragma unroll
-                        for (int t = R_AMAX; t <= R_VINC; ++t)
-                            if (group_of(t) == g2 && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; best = t; }
-                        if (best >= 0) set_code(L, best, 2);
+                            for (int t = R_AMAX; t <= R_VINC; ++t)
+                                if (group_of(t) == g2 && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
+                            if (bestt >= 0) set_code(L, bestt, 2);
+                        }
                     }
                 }
-                any = __any(changed);
             }
-            if (!any) ok = true;
+            if (single) {
+                wave_argmax(worst, fix);
+                if (fix != 0x7fffffff) {
+                    changed = 1;
+                    const int ek = fix >> 16, el = (fix >> 5) & 63, et = fix & 31;
+                    if (lane == el) {
+                        if (ek == EV_DROP) set_code(L, et, 0);
+                        else if (ek == EV_COMPL) set_code(L, et, 3);
+                        else {
+                            int p = pivot_of(L, et);
+                            if (p >= 0) set_code(L, p, 0);
+                            int bestt = -1; double bl = -1e300;
+#pragma unroll
+                            for (int t = R_AMAX; t <= R_VINC; ++t)
+                                if (group_of(t) == et && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
+                            if (bestt >= 0) set_code(L, bestt, 2);
+                        }
+                    }
+                }
+            }
+            if (!__any(changed)) ok = true;
         }
         if (!ok) {
             L.code = 0ull;           // cold start
@@ -582,6 +617,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
     const double* none = nullptr; (void)none;
     for (;;) {
         refine_primal(L, c, M, Hs, m, 0.0, 0, 0, 0, 0, 0, grad_total, 3);
+        scatter_to_types<MMAX>(L, M.lam, L.lamt);
         // most violated inactive row / group bound.  Anti-cycling: rounding noise of the order of
         // (largest multiplier) x eps can flip rows in and out at the tightest tolerance (seen with
         // the ORIG weights, w_f = 1e7); the tolerance is relaxed decade by decade if the iteration
@@ -595,7 +631,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             double myb = tolv; int myp = -1;
 #pragma unroll
             for (int t = 0; t < kNumRowTypes; ++t) {
-                if (!((L.valid >> t) & 1u)) continue;
+                if (!((L.valid >> t) & 1u) || ((L.ign >> t) & 1u)) continue;
                 if (code_of(L, t) != 0) continue;
                 int g2 = lane_group(L, t);
                 double val = row_val(L, c, t, L.ba[t]);
@@ -604,9 +640,14 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 if (sc > myb) { myb = sc; myp = t; }
             }
             if (lane < N) {
-                if (pivot_of(L, G_F) >= 0 && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 16 + G_F; }
-                if (pivot_of(L, G_S) >= 0 && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 16 + G_S; }
-                if (pivot_of(L, G_V) >= 0 && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
+                if (pivot_of(L, G_F) >= 0 && !((L.ign >> (16 + G_F)) & 1u) && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 16 + G_F; }
+                if (pivot_of(L, G_S) >= 0 && !((L.ign >> (16 + G_S)) & 1u) && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 16 + G_S; }
+                if (pivot_of(L, G_V) >= 0 && !((L.ign >> (16 + G_V)) & 1u) && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
+                // quadratic slack of a compliant row: xi_h = (Lambda - w)/q must stay above its bound
+                if (code_of(L, R_HWP) == 3 && !((L.ign >> (16 + G_H)) & 1u)) {
+                    double xih = (L.lamt[R_HWP] - c.wH) / c.qH;
+                    if (L.lbH - xih > myb) { myb = L.lbH - xih; myp = 16 + G_H; }
+                }
             }
             best = myb; bp = (myp < 0) ? 0x7fffffff : (lane * 32 + myp);
             wave_argmax(best, bp);
@@ -621,6 +662,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         double lam_q = 0.0;
         bool inc_compl = false;
         bool finished = false;
+        bool first_pass = true;
         while (!finished) {
             if (++st.events > 40 * max_iter) { st.status = 2; finished = true; break; }
             // effective incoming row (computed on lane kq, broadcast)
@@ -644,6 +686,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                             qd -= pba;
                         } else qd += group_lb(L, gq);
                     }
+                } else if (gq == G_H) {
+                    qal = -row_al(R_HWP); qbe = -row_be(R_HWP, c.tau_min, L.chw);
+                    qd = -(L.ba[R_HWP] + L.lbH);
                 } else {
                     int p = pivot_of(L, gq);
                     double pba = 0.0;
@@ -655,7 +700,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             }
             qal = bcast(qal, kq); qbe = bcast(qbe, kq); qga = bcast(qga, kq); qde = bcast(qde, kq);
             qd = bcast(qd, kq); qD = bcast(qD, kq);
-            // multipliers of the working set for the current incoming multiplier
+            // multipliers of the working set for the current incoming multiplier (the first pass
+            // of an iteration starts from the state the loop head has just computed)
+            if (!first_pass) {
             m = rebuild_and_factor(L, c, M, Hs, tauv);
             if (m < 0) { st.status = 2; finished = true; break; }
             {
@@ -671,6 +718,8 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 if (m > 0) solve_multipliers(M, m, lane, N);
             }
             refine_primal(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total, 3);
+            }
+            first_pass = false;
             double viol = qal * M.shv[kq] + qbe * M.vhv[kq] - qD * lam_q - qd;
             if (kq < N) viol += qga * M.av[kq];
             if (kq > 0) viol += qde * M.av[kq - 1];
@@ -698,7 +747,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 sr = wave_sum(sr);
             }
             const double zz = cu - sr + qD;
-            double t2 = (zz > 1e-10 * (cu + qD)) ? viol / zz : kInf;
+            double t2 = (zz > 1e-8 * (cu + qD)) ? viol / zz : kInf;
             if (viol <= 0.0) t2 = 0.0;
             // blocking events, evaluated per (lane, type)
             scatter_to_types<MMAX>(L, M.lam, L.lamt);
@@ -714,7 +763,10 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                     double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
                     if (g2 == G_H) {
                         if (cd == 3) {
-                            if (r > 0.0) { double tt = fmax(l - c.wH, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_RIGID << 16) | (lane << 5) | t; } }
+                            // the row's own multiplier is Lambda - mu (mu: multiplier of an incoming slack bound)
+                            if (lane == kq && q_is_bound && gq == G_H) {
+                                if (r + 1.0 > 0.0) { double tt = fmax(l - lam_q, 0.0) / (r + 1.0); if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | t; } }
+                            } else if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
                         } else {
                             if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
                             else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
@@ -744,12 +796,20 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 wave_argmin(t1, ev);
             }
             const double tstep = fmin(t1, t2);
-            if (!(tstep < 1e299)) { st.status = 1; finished = true; break; }
+            if (!(tstep < 1e299)) {
+                // the incoming normal lies in the span of the working set and nothing can be
+                // dropped.  With a real violation the QP is infeasible; with a rounding-level one
+                // the row is a duplicate of active rows (e.g. a_k pinned by an acceleration AND a
+                // jerk limit): mark it as ignored for this solve.
+                if (best < 1e-7) { if (lane == kq) L.ign |= (1u << qcode); finished = true; break; }
+                st.status = 1; finished = true; break;
+            }
             lam_q += tstep;
             if (t2 <= t1) {
                 // full step: the incoming constraint becomes active
                 if (lane == kq) {
                     if (!q_is_bound) set_code(L, tq, inc_compl ? 3 : 1);
+                    else if (gq == G_H) set_code(L, R_HWP, 1);      // compliant row turns rigid
                     else { int p = pivot_of(L, gq); set_code(L, p, 1); }
                 }
                 finished = true;
@@ -757,7 +817,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
                 if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
                 else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
-                else if (ek == EV_RIGID) { if (lane == el) set_code(L, et, 1); }
+                else if (ek == EV_DROPH) { if (lane == el) set_code(L, et, 0); finished = true; }
                 else if (ek == EV_CAPIN) { inc_compl = true; }
                 else if (ek == EV_CAP) {
                     int fin = 0;
@@ -1019,6 +1079,7 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const
         if (exists) valid |= (1u << t);
     }
     L.valid = valid;
+    L.ign = 0u;
     // drop warm-start codes of rows that do not exist at this lane
     L.code = code;
 #pragma unroll
@@ -1065,6 +1126,9 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const
     so.out[EEPACC_OUT_DISTHOR] = dist_hor;
     so.out[EEPACC_OUT_AQP] = a0;
     so.status = (st.status != 0 || __any(infeasible_const)) ? 1 : 0;
+#ifdef EEPACC_DEBUG_STATUS
+    if (so.status) so.status = st.status * 100000 + (__any(infeasible_const) ? 10000 : 0) + (st.m + 100) + 1000 * 0;
+#endif
 #ifdef EEPACC_DEBUG_STATUS
     so.iters = st.iters + 100000 * st.status + 1000000 * (__any(infeasible_const) ? 1 : 0) + 10000000 * st.m;
 #else

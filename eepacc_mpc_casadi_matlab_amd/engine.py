@@ -119,9 +119,10 @@ class Engine:
         return out, sp, vp, status
 
     # B1 ------------------------------------------------------------------------------------
-    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False):
+    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False, out=None):
         """s_tv, v_tv: [n_steps, B] lead traces.  Returns traj [n_steps, OUT_N, B], status [n_steps, B].
-        resume=True continues the simulation of the previous call (s_tv/v_tv hold the next rows)."""
+        resume=True continues the simulation of the previous call (s_tv/v_tv hold the next rows).
+        out=(traj, status): preallocated output tensors to write into."""
         t = self.torch
         if not resume:
             self.reset()
@@ -129,8 +130,12 @@ class Engine:
         v_tv = t.as_tensor(v_tv, dtype=t.float64, device=self.device).contiguous()
         n_steps, B = s_tv.shape
         ins = [self._d(x, B) for x in (s0, v0, a_minus1)]
-        traj = t.empty((n_steps, OUT_N, B), dtype=t.float64, device=self.device)
-        status = t.empty((n_steps, B), dtype=t.int32, device=self.device)
+        if out is not None:
+            traj, status = out[0][:n_steps], out[1][:n_steps]
+            assert traj.shape == (n_steps, OUT_N, B) and traj.is_contiguous() and status.is_contiguous()
+        else:
+            traj = t.empty((n_steps, OUT_N, B), dtype=t.float64, device=self.device)
+            status = t.empty((n_steps, B), dtype=t.int32, device=self.device)
         _check(self.lib.eepacc_run_abmpc(self.h, B, n_steps, *[x.data_ptr() for x in ins], s_tv.data_ptr(),
                                          v_tv.data_ptr(), traj.data_ptr(), status.data_ptr(), self._stream()))
         return traj, status

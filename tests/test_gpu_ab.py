@@ -96,8 +96,8 @@ def test_open_loop_seeded_batch_vs_oracle(tree, N, B, torch_mod):
             assert abs(o[OUT[n], i] - r["out"][OUT[n]]) < t, (i, n)
         ctol = 1e-6 if tree == "ORIG" else 1e-8
         assert abs(o[OUT["cost"], i] - r["out"][OUT["cost"]]) < ctol * (1 + abs(r["out"][OUT["cost"]])), i
-        assert np.abs(sp[:, i] - r["s_pred"]).max() < 1e-8
-        assert np.abs(vp[:, i] - r["v_pred"]).max() < 1e-9
+        assert np.abs(sp[:, i] - r["s_pred"]).max() < (1e-6 if tree == "ORIG" else 1e-8)
+        assert np.abs(vp[:, i] - r["v_pred"]).max() < (1e-7 if tree == "ORIG" else 1e-9)
 
 
 def test_closed_loop_s2_vs_oracle(torch_mod, lead_trace):

@@ -210,6 +210,8 @@ class StructuredQP:
         self.iters = 0
         self.events = 0
         self.refine_rounds = 2
+        self.warm_tol = 1e-12
+        self.single_passes = 8
 
     # effective (a-space) normal / rhs / compliance of a working-set row
     def eff(self, j):
@@ -318,8 +320,8 @@ class StructuredQP:
             if sc > best:
                 best, bq = sc, ("row", j)
         for g, st in self.gstate.items():
-            if st["P"]:
-                G = self.p.groups[g]
+            G = self.p.groups[g]
+            if st["P"] or (G["q"] > 0 and st["compl"]):
                 val = G["lb"] - self.xi(g, a)
                 if val > best:
                     best, bq = val, ("bound", g)
@@ -339,6 +341,9 @@ class StructuredQP:
             lb = self.p.groups[g]["lb"] if g is not None else 0.0
             return r["n"], r["b"] + lb, 0.0
         g = q[1]
+        if self.p.groups[g]["q"] > 0:      # bound of a quadratic slack whose row is compliant
+            pr = self.p.rows[self.p.groups[g]["rows"][0]]
+            return -pr["n"], -(pr["b"] + self.p.groups[g]["lb"]), 0.0
         pr = self.p.rows[self.gstate[g]["pivot"]]
         return -pr["n"], -(pr["b"] + self.p.groups[g]["lb"]), 0.0
 
@@ -383,7 +388,7 @@ class StructuredQP:
                 s = self.C @ u if m else np.zeros(0)
                 r = self.Pm @ s if m else np.zeros(0)
                 zz = c @ u - (s @ r if m else 0.0) + Dq
-                t2 = viol / zz if zz > 1e-13 * (1 + c @ u) else math.inf
+                t2 = viol / zz if zz > 1e-8 * (c @ u + Dq) else math.inf
                 if viol <= 0:
                     t2 = 0.0
                 # blocking events
@@ -394,9 +399,14 @@ class StructuredQP:
                     if g is not None and p.groups[g]["q"] > 0:
                         G = p.groups[g]
                         if self.gstate[g]["compl"]:
-                            if r[i] > 0:                       # decreasing towards w
-                                t = (lam - G["w"]) / r[i]
-                                if t < t1: t1, ev = t, ("rigid", j)
+                            # multiplier of the row itself = Lambda - mu must stay >= 0
+                            if q[0] == "bound" and q[1] == g:
+                                if r[i] + 1.0 > 0:
+                                    t = max(lam - lam_q, 0.0) / (r[i] + 1.0)
+                                    if t < t1: t1, ev = t, ("drop_h", j)
+                            elif r[i] > 0:
+                                t = lam / r[i]
+                                if t < t1: t1, ev = t, ("drop", j)
                         else:
                             if r[i] > 0:
                                 t = lam / r[i]
@@ -446,8 +456,13 @@ class StructuredQP:
             j = q[1]
             self.W.append(j); self.lam[j] = lam_q
             return
-        # bound of a P group became active: group -> Z, pivot becomes an ordinary row
         g = q[1]
+        if self.p.groups[g]["q"] > 0:
+            # bound of a quadratic slack became active: the compliant row turns rigid
+            # (its multiplier Lambda - mu is recomputed from the working set)
+            self.gstate[g]["compl"] = False
+            return
+        # bound of a P group became active: group -> Z, pivot becomes an ordinary row
         st = self.gstate[g]
         piv = st["pivot"]
         lam_p = self.group_margin(g, lam_q, q)      # w - others - mu
@@ -466,10 +481,12 @@ class StructuredQP:
             g = p.rows[ev[1]]["grp"]; self.gstate[g]["compl"] = True
             self.lam[ev[1]] = p.groups[g]["w"]
             return False
-        if kind == "rigid":
-            g = p.rows[ev[1]]["grp"]; self.gstate[g]["compl"] = False
-            self.lam[ev[1]] = p.groups[g]["w"]
-            return False
+        if kind == "drop_h":
+            # the incoming bound of a quadratic slack takes over: the row leaves, xi sits on its bound
+            j = ev[1]; g = p.rows[j]["grp"]
+            self.W.remove(j); del self.lam[j]
+            self.gstate[g]["compl"] = False
+            return True
         if kind == "cap_in":
             # incoming Huber row reached lambda = w before becoming tight: its slack leaves the
             # bound (xi_h > 0); the row keeps coming in, now as a compliant row
@@ -550,7 +567,7 @@ def shift_states(st, N):
     return out
 
 
-def warm_start(qp: StructuredQP, st, max_pass=8):
+def warm_start(qp: StructuredQP, st, max_pass=16):
     p = qp.p
     index = {(r["name"], r["k"]): j for j, r in enumerate(p.rows)}
     for key, code in st.items():
@@ -581,36 +598,72 @@ def warm_start(qp: StructuredQP, st, max_pass=8):
                 g.update(P=False, pivot=None, compl=False)
             qp.factor(); return False
         bad = False
-        tol = 1e-12
+        lam_max = max([abs(v) for v in qp.lam.values()] + [0.0])
+        tol = qp.warm_tol * (1.0 + lam_max)
+        # collect violations of dual feasibility, repair only the worst one per pass
+        worst, fix = tol, None
         for j in list(qp.W):
             g = p.rows[j]["grp"]; lam = qp.lam[j]
             if g is not None and p.groups[g]["q"] > 0:
                 G = p.groups[g]
                 if qp.gstate[g]["compl"]:
-                    if lam < G["w"] - tol:
-                        qp.gstate[g]["compl"] = False; bad = True
+                    if -lam > worst: worst, fix = -lam, ("drop", j)
                 else:
-                    if lam < -tol:
-                        qp.W.remove(j); bad = True
-                    elif lam > G["w"] + tol:
-                        qp.gstate[g]["compl"] = True; bad = True
-            elif lam < -tol:
-                qp.W.remove(j); bad = True
-        if not bad:
-            for g, s in qp.gstate.items():
+                    if -lam > worst: worst, fix = -lam, ("drop", j)
+                    if lam - G["w"] > worst: worst, fix = lam - G["w"], ("compl", j)
+            elif -lam > worst:
+                worst, fix = -lam, ("drop", j)
+        for g, s_ in qp.gstate.items():
+            G = p.groups[g]
+            if G["q"] > 0:
+                continue
+            mg = qp.group_margin(g)
+            if -mg > worst:
+                worst, fix = -mg, ("cap", g)
+        if fix is not None and it >= qp.single_passes:
+            # mass repair: every violation at once (keeps the pivots, unlike a cold start)
+            bad = True
+            for j in list(qp.W):
+                g = p.rows[j]["grp"]; lam = qp.lam[j]
+                if g is not None and p.groups[g]["q"] > 0:
+                    G = p.groups[g]
+                    if qp.gstate[g]["compl"]:
+                        if lam < -tol:
+                            qp.W.remove(j); qp.gstate[g]["compl"] = False
+                    elif lam < -tol: qp.W.remove(j)
+                    elif lam > G["w"] + tol: qp.gstate[g]["compl"] = True
+                elif lam < -tol:
+                    qp.W.remove(j)
+            for g, s_ in qp.gstate.items():
                 G = p.groups[g]
                 if G["q"] > 0:
                     continue
-                mg = qp.group_margin(g)
-                if mg < -tol:
-                    members = [j for j in qp.W if p.rows[j]["grp"] == g]
-                    bad = True
+                members = [j for j in qp.W if p.rows[j]["grp"] == g]
+                mg = G["w"] - sum(max(qp.lam[j], 0.0) for j in members)
+                if mg < -tol * (1 + G["w"]):
                     if members:
                         piv = max(members, key=lambda j: qp.lam[j])
-                        qp.W.remove(piv)
-                        s["P"] = True; s["pivot"] = piv
+                        qp.W.remove(piv); s_["P"] = True; s_["pivot"] = piv
                     else:
-                        s["P"] = False; s["pivot"] = None
+                        s_["P"] = False; s_["pivot"] = None
+        elif fix is not None:
+            bad = True
+            if fix[0] == "drop":
+                qp.W.remove(fix[1])
+                gg = p.rows[fix[1]]["grp"]
+                if gg is not None and p.groups[gg]["q"] > 0:
+                    qp.gstate[gg]["compl"] = False
+            elif fix[0] == "compl":
+                qp.gstate[p.rows[fix[1]]["grp"]]["compl"] = True
+            else:
+                g = fix[1]; s_ = qp.gstate[g]
+                members = [j for j in qp.W if p.rows[j]["grp"] == g]
+                if members:
+                    piv = max(members, key=lambda j: qp.lam[j])
+                    qp.W.remove(piv)
+                    s_["P"] = True; s_["pivot"] = piv
+                else:
+                    s_["P"] = False; s_["pivot"] = None
         if not bad:
             qp.factor()
             return True
