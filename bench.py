@@ -58,8 +58,8 @@ def main():
     from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
     from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from eepacc_mpc_casadi_matlab_amd.distributed import rank_world, shard_range, reduce_kpis, max_over_ranks
+    rank, world, local_rank = rank_world()
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -68,7 +68,8 @@ def main():
     N, B, K, W = args.horizon, args.batch, args.steps, args.warmup
     OPT, V, _, _ = make_case("ABO", N)
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
-    sc = make_s2(B, W + K, lead["V_TO_2Hz"], first_instance=rank * B)   # shard: rank r owns instances [rB, (r+1)B)
+    lo, _ = shard_range(rank, world, B)                                  # rank r owns instances [rB, (r+1)B)
+    sc = make_s2(B, W + K, lead["V_TO_2Hz"], first_instance=lo)
     eng = Engine(OPT, V, device=dev, max_batch=B)
     d = torch.device("cuda", dev)
     s_tv = torch.as_tensor(sc["s_tv"], device=d); v_tv = torch.as_tensor(sc["v_tv"], device=d)
@@ -90,9 +91,7 @@ def main():
     # timed region launches (ours and torch's small reductions, which are loaded lazily)
     if W > 0:
         tw, sw = run(0, W, False)
-        kw = kpis(tw, sw.sum())
-        if world > 1:
-            dist.all_reduce(kw, op=dist.ReduceOp.SUM)
+        kw = reduce_kpis(kpis(tw, sw.sum()), world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -113,19 +112,14 @@ def main():
         k = hi
     ev1.record(stream)
     # KPI reduction (the only collective of the job): bad exits, distance, sum a^2
-    kpi = kpis(traj, bad)
-    if world > 1:
-        dist.all_reduce(kpi, op=dist.ReduceOp.SUM)
+    kpi = reduce_kpis(kpis(traj, bad), world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=d)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt, world, d)
     iters = eng.last_iterations(B)
 
     if rank == 0:
@@ -137,6 +131,13 @@ def main():
         launch_s = (kernel_ms / 1e3) / launches
         qp_per_launch = B * (K / launches)
         achieved_mat = bytes_mat * qp_per_launch / launch_s / 1e9
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, KB units, raw)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
+            per_qp = (prof["pmc"]["FETCH_SIZE"] + prof["pmc"]["WRITE_SIZE"]) * 1024.0 / (4096 * 200)
+            traffic = per_qp * qp_per_launch
+        except Exception:
+            pass
         res = {
             "metric": "QP steps/sec (whole node), ABMPC N=30 dense QP at batch 4096",
             "value": value, "unit": "QP steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -146,7 +147,7 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "steps_per_launch": int(K / launches),
                        "parallelism": "instances sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved_mat, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved_mat / 8000.0, "traffic": None,
+                         "frac": achieved_mat / 8000.0, "traffic": traffic,
                          "definition": "R-materialised (SURVEY.md 8d): bytes the reference's dense-QP API moves per QP step "
                                        "(%d B at N=%d) x QP steps per launch / mean k_run_abmpc launch time (HIP events); "
                                        "the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it"

@@ -12,11 +12,11 @@ import numpy as np
 
 def make_s2(B: int, n_steps: int, V_TO_2Hz: np.ndarray, Ts: float = 0.5, seed: int = 1234,
             first_instance: int = 0):
-    rng = np.random.default_rng(seed)
+    # one stream per quantity, so that instance i gets the same draw whatever the shard size
     total = first_instance + B
-    v0_all = rng.uniform(0.0, 10.0, total)
-    scale_all = rng.uniform(0.8, 1.2, total)
-    gap_all = rng.uniform(6.0, 40.0, total)
+    v0_all = np.random.default_rng([seed, 0]).uniform(0.0, 10.0, total)
+    scale_all = np.random.default_rng([seed, 1]).uniform(0.8, 1.2, total)
+    gap_all = np.random.default_rng([seed, 2]).uniform(6.0, 40.0, total)
     idx = np.arange(first_instance, total)
     v0, scale, gap = v0_all[idx], scale_all[idx], gap_all[idx]
     base = np.where(np.asarray(V_TO_2Hz, dtype=np.float64) < 0.1, 0.0, V_TO_2Hz)   # Run_DrivingCycle.m:17
