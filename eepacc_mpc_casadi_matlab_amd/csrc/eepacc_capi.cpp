@@ -147,35 +147,12 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         }
     }
     if (!spd_inverse(H, N)) return fail(EEPACC_EINVAL, "condensed Hessian is not positive definite");
-    // device tables: [Hinv N x N][HSs (N+1) x N][HSv (N+1) x N] with HSs[k][j] = (Hinv Ss[k]')_j,
-    // Ss/Sv the condensing rows of TransformToDenseFormulation.m:46-52 for A=[1 T;0 1], B=[T^2/2;T]
-    Hinv.assign((size_t)N * N + 2 * (size_t)(N + 1) * N, 0.0);
+    Hinv.assign((size_t)N * N, 0.0);
     for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) {
-            long double h = 0.5L * (H[(size_t)i * N + j] + H[(size_t)j * N + i]);
-            H[(size_t)i * N + j] = h;
-        }
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) { H[(size_t)j * N + i] = H[(size_t)i * N + j]; Hinv[(size_t)i * N + j] = (double)H[(size_t)i * N + j]; }
-    std::vector<long double> Sv((size_t)(N + 1) * N, 0.0L), Ss((size_t)(N + 1) * N, 0.0L);
-    for (int k = 0; k < N; ++k)
-        for (int j = 0; j < N; ++j) {
-            long double T = C.Tvec[k];
-            Sv[(size_t)(k + 1) * N + j] = Sv[(size_t)k * N + j] + (j == k ? T : 0.0L);
-            Ss[(size_t)(k + 1) * N + j] = Ss[(size_t)k * N + j] + T * Sv[(size_t)k * N + j] + (j == k ? 0.5L * T * T : 0.0L);
-        }
-    double* HSs = Hinv.data() + (size_t)N * N;
-    double* HSv = HSs + (size_t)(N + 1) * N;
-    for (int k = 0; k <= N; ++k)
-        for (int j = 0; j < N; ++j) {
-            long double as = 0.0L, av = 0.0L;
-            for (int i = 0; i < N; ++i) {
-                as += H[(size_t)j * N + i] * Ss[(size_t)k * N + i];
-                av += H[(size_t)j * N + i] * Sv[(size_t)k * N + i];
-            }
-            HSs[(size_t)k * N + j] = (double)as;
-            HSv[(size_t)k * N + j] = (double)av;
-        }
+        for (int j = 0; j < N; ++j)
+            Hinv[(size_t)i * N + j] = (double)(0.5L * (H[(size_t)i * N + j] + H[(size_t)j * N + i]));
+    if (eepacc::ab_smem_bytes(N) > 160 * 1024)
+        return fail(EEPACC_ENOTSUP, "N_hor too large for the LDS layout of this build");
     return EEPACC_OK;
 }
 

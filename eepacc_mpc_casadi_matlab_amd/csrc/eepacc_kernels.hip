@@ -119,12 +119,13 @@ __device__ __forceinline__ double row_de(int t, int k) {
 }
 
 template <int MMAX>
-struct WaveMem {                 // one per wave, in LDS
+struct WaveMem {                 // one per wave, in LDS (followed by the wave's N x N matrix He)
     double P[MMAX * (MMAX + 1) / 2];
-    double yv[64], ub[64], av[64];
-    double sub[65], vub[65], shv[65], vhv[65];
-    double ws[65], wv[65], wa[65 + 3 * 65];   // wa[65..] scratch of adjoint()
-    double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX], e_D[MMAX];
+    double yv[64], av[64];
+    double shv[65], vhv[65];
+    double ub[65], sub[65], vub[65];          // images of a vector; also scratch of adjoint()
+    double ws[65], wv[65], wa[65];
+    double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX];
     double lam[MMAX], sv[MMAX], rv[MMAX], colk[MMAX];
     int w_k[MMAX];
 };
@@ -139,6 +140,7 @@ struct Lane {
     double ba[kNumRowTypes];      // a-space right-hand sides
     unsigned valid;               // bit t: row (t, lane) exists with a non-zero normal
     unsigned ign;                 // bit t / 16+g: duplicate row ignored during this solve
+    unsigned long long kmask;     // wave-uniform: stages whose penalty q n n' is folded into He
     double lbF, lbS, lbV, lbH;    // slack lower bounds (constant rows of stage 0 fold in here)
     unsigned long long code;      // 4 bits per type: 0 off, 1 in working set, 2 group pivot, 3 compliant
     double chw;                   // headway-policy coefficient T_hwp + G_hwp*v_est(k)
@@ -203,17 +205,6 @@ __device__ __forceinline__ double hinv_mul(const double* __restrict__ Hs, const 
     return lane < N ? (a0 + a1) + (a2 + a3) : 0.0;
 }
 
-// u = Hinv c for a structured row c = al*Ss[kq]' + be*Sv[kq]' + ga*e_kq + de*e_{kq-1}: a combination of
-// columns of the precomputed tables Hinv*Ss', Hinv*Sv' ([k][j], k = 0..N) and of Hinv itself (LDS)
-__device__ __forceinline__ double hinv_row(const double* Hs, const double* HSs, const double* HSv, int N, int lane,
-                                           int kq, double al, double be, double ga, double de) {
-    if (lane >= N) return 0.0;
-    double u = al * HSs[kq * N + lane] + be * HSv[kq * N + lane];
-    if (kq < N && ga != 0.0) u += ga * Hs[kq * N + lane];
-    if (kq > 0 && de != 0.0) u += de * Hs[(kq - 1) * N + lane];
-    return u;
-}
-
 // a-space normal of the row (kq; al,be,ga,de) evaluated at this lane j:
 __device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, double be, double ga, double de, double tau_kq) {
     double c = 0.0;
@@ -228,7 +219,7 @@ __device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, do
 
 // adjoint of the condensing: given stage weights on (s_k, v_k, a_k) in LDS (ws, wv, wa, k = 0..N)
 // returns d/da_j of sum_k ws_k s_k + wv_k v_k + wa_k a_k  for lane j < N
-__device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, double* wa) {
+__device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, const double* wa, double* tmp) {
     // suffix sums over stages k > j are prefix sums over the reversed stage order: lane r holds
     // stage N - r; the three running sums are written back in stage order through LDS (wa[65..])
     const int r = L.lane, N = L.N;
@@ -237,7 +228,6 @@ __device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const
     const double s = in ? ws[k] : 0.0, v = in ? wv[k] : 0.0;
     const double tk = in ? L.tau_rev : 0.0;
     const double WS = scan_excl(s), WV = scan_excl(v), WST = scan_excl(s * tk);
-    double* tmp = wa + 65;
     if (in) { tmp[k] = WS; tmp[65 + k] = WV; tmp[130 + k] = WST; }
     WSYNC();
     const int j = L.lane;
@@ -251,18 +241,68 @@ enum Ev : int { EV_NONE = 0, EV_DROP, EV_COMPL, EV_DROPH, EV_CAP, EV_CAPIN };
 
 struct SolveStats { int status, iters, events, m; };
 
+// The quadratic slack xi_h of stage k, once above its bound, is eliminated into the objective:
+// H_eff = H + q * sum_k n_k n_k'  (n_k: a-space normal of the headway-policy row).  He holds
+// H_eff^-1 for this wave; adding / removing one stage is a Sherman-Morrison rank-one update.
+template <int MMAX>
+__device__ __forceinline__ void he_rank1(const Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* He,
+                                         const double* tauv, int k, bool add) {
+    const int lane = L.lane, N = L.N;
+    const double chwk = bcast(L.chw, k);
+    const double nk = normal_at(L, k, 1.0, chwk, 0.0, 0.0, tauv[k]);
+    if (lane < N) M.yv[lane] = nk;
+    WSYNC();
+    const double y = hinv_mul(He, M.yv, N, lane);
+    double sy, vy;
+    hom_traj(L, y, sy, vy);
+    const double ny = bcast(sy + chwk * vy, k);                 // n_k' y
+    const double kappa = add ? c.qH / (1.0 + c.qH * ny) : -c.qH / (1.0 - c.qH * ny);
+    if (lane < N) M.ub[lane] = y;
+    WSYNC();
+    if (lane < N) {
+        const double yj = kappa * y;
+        int i = 0;
+        for (; i + 4 <= N; i += 4) {
+            const double h0 = He[(i + 0) * N + lane], h1 = He[(i + 1) * N + lane], h2 = He[(i + 2) * N + lane], h3 = He[(i + 3) * N + lane];
+            const double y0 = M.ub[i], y1 = M.ub[i + 1], y2 = M.ub[i + 2], y3 = M.ub[i + 3];
+            He[(i + 0) * N + lane] = fma(-y0, yj, h0); He[(i + 1) * N + lane] = fma(-y1, yj, h1);
+            He[(i + 2) * N + lane] = fma(-y2, yj, h2); He[(i + 3) * N + lane] = fma(-y3, yj, h3);
+        }
+        for (; i < N; ++i) He[i * N + lane] = fma(-M.ub[i], yj, He[i * N + lane]);
+    }
+    WSYNC();
+}
+
+template <int MMAX>
+__device__ __forceinline__ void he_sync(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* He, const double* tauv) {
+    const unsigned long long want = __ballot(L.lane < L.N && code_of(L, R_HWP) == 3);
+    unsigned long long diff = want ^ L.kmask;
+    while (diff) {
+        const int k = __ffsll((long long)diff) - 1;
+        diff &= diff - 1;
+        he_rank1(L, c, M, He, tauv, k, ((want >> k) & 1ull) != 0ull);
+    }
+    L.kmask = want;
+}
+
+__device__ __forceinline__ void he_load_base(double* He, const double* __restrict__ base, int N, int lane) {
+    const int n2 = N * N;
+    for (int i = lane; i < n2; i += 64) He[i] = base[i];
+}
+
 // ----------------------------------------------------------------------------------------------
 // rebuild the working-set list + effective rows from the state codes, build S = C Hinv C' + D,
 // invert it in place (symmetric sweeps).  returns m (or -1 if S was numerically singular).
 template <int MMAX>
-__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, const double* tauv) {
+__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* Hs, const double* tauv) {
     const int lane = L.lane, N = L.N;
+    he_sync(L, c, M, Hs, tauv);
     // count this lane's active rows
     int cnt = 0;
 #pragma unroll
     for (int t = 0; t < kNumRowTypes; ++t) {
         int cd = code_of(L, t);
-        cnt += (cd == 1 || cd == 3) ? 1 : 0;
+        cnt += (cd == 1) ? 1 : 0;
     }
     double basef = scan_excl((double)cnt);
     L.base = (int)(basef + 0.5);
@@ -273,13 +313,12 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
 #pragma unroll
     for (int t = 0; t < kNumRowTypes; ++t) {
         int cd = code_of(L, t);
-        if (cd == 1 || cd == 3) {
+        if (cd == 1) {
             int g = lane_group(L, t);
             double al = row_al(t), be = row_be(t, c.tau_min, L.chw), ga = row_ga(t), de = row_de(t, lane);
-            double d = L.ba[t], D = 0.0;
+            double d = L.ba[t];
             if (g == G_H) {
-                if (cd == 3) { d -= c.wH / c.qH; D = 1.0 / c.qH; }
-                else d += L.lbH;
+                d += L.lbH;
             } else if (g != G_NONE) {
                 int p = (g == G_F) ? pF : (g == G_S ? pS : pV);
                 if (p >= 0) {
@@ -293,18 +332,19 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
                 }
             }
             M.e_al[pos] = al; M.e_be[pos] = be; M.e_ga[pos] = ga; M.e_de[pos] = de;
-            M.e_d[pos] = d; M.e_D[pos] = D; M.w_k[pos] = lane;
+            M.e_d[pos] = d; M.w_k[pos] = lane;
             ++pos;
         }
     }
     WSYNC();
     if (m == 0) return 0;
-    // S columns
-    const double* HSs = Hs + N * N;
-    const double* HSv = HSs + (N + 1) * N;
+    // S columns: u_j = He c_j
     for (int j = 0; j < m; ++j) {
         const int kj = M.w_k[j];
-        double u = hinv_row(Hs, HSs, HSv, N, lane, kj, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j]);
+        double cj = normal_at(L, kj, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj]);
+        if (lane < N) M.yv[lane] = cj;
+        WSYNC();
+        double u = hinv_mul(Hs, M.yv, N, lane);
         double su, vu;
         hom_traj(L, u, su, vu);
         if (lane < N) M.ub[lane] = u;
@@ -315,7 +355,6 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
             double sx = M.e_al[lane] * M.sub[ki] + M.e_be[lane] * M.vub[ki];
             if (ki < N) sx += M.e_ga[lane] * M.ub[ki];
             if (ki > 0 && ki <= N) sx += M.e_de[lane] * M.ub[ki - 1];
-            if (lane == j) sx += M.e_D[lane];
             M.P[pidx(lane, j)] = sx;
         }
         WSYNC();
@@ -381,6 +420,11 @@ __device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, Wav
             }
         }
     }
+    if (lane < N && code_of(L, R_HWP) == 3) {
+        // quadratic slack above its bound: penalty w*xi + q/2 xi^2, xi = n'a - b; linear part (w - q b) n
+        const double wl = c.wH - c.qH * L.ba[R_HWP];
+        s += wl * row_al(R_HWP); v += wl * row_be(R_HWP, c.tau_min, L.chw);
+    }
     if (lane <= N) { M.ws[lane] = s; M.wv[lane] = v; M.wa[lane] = a0; }
     WSYNC();
     if (lane > 0 && lane < N && a1 != 0.0) atomicAdd(&M.wa[lane - 1], a1);
@@ -399,7 +443,7 @@ __device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, Wav
         if (kq > 0 && qde != 0.0) atomicAdd(&M.wa[kq - 1], lam_q * qde);
     }
     WSYNC();
-    double g = adjoint(L, M.ws, M.wv, M.wa);
+    double g = adjoint(L, M.ws, M.wv, M.wa, M.ub);
     return (lane < N) ? g + L.g0 : 0.0;
 }
 
@@ -439,7 +483,7 @@ __device__ __forceinline__ void scatter_to_types(const Lane& L, const double* x,
     for (int t = 0; t < kNumRowTypes; ++t) {
         int cd = code_of(L, t);
         double v = 0.0;
-        if (cd == 1 || cd == 3) { v = x[pos]; ++pos; }
+        if (cd == 1) { v = x[pos]; ++pos; }
         out[t] = v;
     }
 }
@@ -475,7 +519,7 @@ __device__ __forceinline__ void refine_primal(Lane& L, const Cfg& c, WaveMem<MMA
     for (int round = 0; round < max_rounds; ++round) {
         double res = 0.0, rel = 0.0;
         if (L.lane < m) {
-            res = rows_dot_img(M, L.lane, L.N, M.av, M.shv, M.vhv) - M.e_D[L.lane] * M.lam[L.lane] - M.e_d[L.lane];
+            res = rows_dot_img(M, L.lane, L.N, M.av, M.shv, M.vhv) - M.e_d[L.lane];
             rel = fabs(res) / (1.0 + fabs(M.e_d[L.lane]));
             M.sv[L.lane] = res;
         }
@@ -507,8 +551,8 @@ __device__ __forceinline__ double group_xi(const Lane& L, const Cfg& c, int g) {
 // the dual active-set solve.  On entry L.code holds the (warm) working set; on exit the optimal
 // one, L.a the accelerations, L.lamt the multipliers per (lane, type).
 template <int MMAX>
-__device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, const double* tauv,
-                               int max_iter, double& grad_total) {
+__device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* Hs, const double* Hbase,
+                               const double* tauv, int max_iter, double& grad_total) {
     const int lane = L.lane, N = L.N;
     SolveStats st{0, 0, 0, 0};
     int m = 0;
@@ -545,14 +589,11 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
 #pragma unroll
             for (int t = 0; t < kNumRowTypes; ++t) {
                 int cd = code_of(L, t);
-                if (cd != 1 && cd != 3) continue;
+                if (cd != 1) continue;
                 int g2 = lane_group(L, t);
                 double l = L.lamt[t];
                 if (g2 == G_H) {
-                    if (cd == 3) {
-                        // xi_h < 0 (multiplier below w) is a primal infeasibility the main loop repairs
-                        if (-l > tol) { if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; } }
-                    } else if (-l > tol) {
+                    if (-l > tol) {
                         if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
                     } else if (l - c.wH > tol) {
                         if (!single) { set_code(L, t, 3); changed = 1; } else if (l - c.wH > worst) { worst = l - c.wH; fix = (EV_COMPL << 16) | (lane << 5) | t; }
@@ -610,6 +651,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         }
         if (!ok) {
             L.code = 0ull;           // cold start
+            he_load_base(Hs, Hbase, N, lane);
+            L.kmask = 0ull;
+            WSYNC();
             m = rebuild_and_factor(L, c, M, Hs, tauv);
         }
     }
@@ -617,7 +661,6 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
     const double* none = nullptr; (void)none;
     for (;;) {
         refine_primal(L, c, M, Hs, m, 0.0, 0, 0, 0, 0, 0, grad_total, 3);
-        scatter_to_types<MMAX>(L, M.lam, L.lamt);
         // most violated inactive row / group bound.  Anti-cycling: rounding noise of the order of
         // (largest multiplier) x eps can flip rows in and out at the tightest tolerance (seen with
         // the ORIG weights, w_f = 1e7); the tolerance is relaxed decade by decade if the iteration
@@ -645,7 +688,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 if (pivot_of(L, G_V) >= 0 && !((L.ign >> (16 + G_V)) & 1u) && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
                 // quadratic slack of a compliant row: xi_h = (Lambda - w)/q must stay above its bound
                 if (code_of(L, R_HWP) == 3 && !((L.ign >> (16 + G_H)) & 1u)) {
-                    double xih = (L.lamt[R_HWP] - c.wH) / c.qH;
+                    double xih = row_val(L, c, R_HWP, L.ba[R_HWP]);
                     if (L.lbH - xih > myb) { myb = L.lbH - xih; myp = 16 + G_H; }
                 }
             }
@@ -660,13 +703,12 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         const int tq = q_is_bound ? -1 : qcode;
         const int gq = q_is_bound ? (qcode - 16) : ((kq == N) ? G_NONE : group_of(qcode));
         double lam_q = 0.0;
-        bool inc_compl = false;
         bool finished = false;
         bool first_pass = true;
         while (!finished) {
             if (++st.events > 40 * max_iter) { st.status = 2; finished = true; break; }
             // effective incoming row (computed on lane kq, broadcast)
-            double qal = 0, qbe = 0, qga = 0, qde = 0, qd = 0, qD = 0;
+            double qal = 0, qbe = 0, qga = 0, qde = 0, qd = 0;
             if (lane == kq) {
                 if (!q_is_bound) {
                     qal = row_al(tq); qbe = row_be(tq, c.tau_min, L.chw); qga = row_ga(tq); qde = row_de(tq, lane);
@@ -675,7 +717,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                     for (int u = 0; u < kNumRowTypes; ++u) if (u == tq) bq = L.ba[u];
                     qd = bq;
                     if (gq == G_H) {
-                        if (inc_compl) { qd -= c.wH / c.qH; qD = 1.0 / c.qH; } else qd += L.lbH;
+                        qd += L.lbH;
                     } else if (gq != G_NONE) {
                         int p = pivot_of(L, gq);
                         if (p >= 0) {
@@ -699,7 +741,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 }
             }
             qal = bcast(qal, kq); qbe = bcast(qbe, kq); qga = bcast(qga, kq); qde = bcast(qde, kq);
-            qd = bcast(qd, kq); qD = bcast(qD, kq);
+            qd = bcast(qd, kq);
             // multipliers of the working set for the current incoming multiplier (the first pass
             // of an iteration starts from the state the loop head has just computed)
             if (!first_pass) {
@@ -720,11 +762,14 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             refine_primal(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total, 3);
             }
             first_pass = false;
-            double viol = qal * M.shv[kq] + qbe * M.vhv[kq] - qD * lam_q - qd;
+            double viol = qal * M.shv[kq] + qbe * M.vhv[kq] - qd;
             if (kq < N) viol += qga * M.av[kq];
             if (kq > 0) viol += qde * M.av[kq - 1];
             // u = Hinv c_q and its trajectories
-            double u = hinv_row(Hs, Hs + N * N, Hs + N * N + (N + 1) * N, N, lane, kq, qal, qbe, qga, qde);
+            double cj = normal_at(L, kq, qal, qbe, qga, qde, tauv[kq]);
+            if (lane < N) M.yv[lane] = cj;
+            WSYNC();
+            double u = hinv_mul(Hs, M.yv, N, lane);
             double su, vu;
             hom_traj(L, u, su, vu);
             if (lane < N) M.ub[lane] = u;
@@ -746,8 +791,8 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 WSYNC();
                 sr = wave_sum(sr);
             }
-            const double zz = cu - sr + qD;
-            double t2 = (zz > 1e-8 * (cu + qD)) ? viol / zz : kInf;
+            const double zz = cu - sr;
+            double t2 = (zz > 1e-8 * cu) ? viol / zz : kInf;
             if (viol <= 0.0) t2 = 0.0;
             // blocking events, evaluated per (lane, type)
             scatter_to_types<MMAX>(L, M.lam, L.lamt);
@@ -758,19 +803,13 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
 #pragma unroll
                 for (int t = 0; t < kNumRowTypes; ++t) {
                     int cd = code_of(L, t);
-                    if (cd != 1 && cd != 3) continue;
+                    if (cd != 1) continue;
                     int g2 = lane_group(L, t);
                     double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
                     if (g2 == G_H) {
-                        if (cd == 3) {
-                            // the row's own multiplier is Lambda - mu (mu: multiplier of an incoming slack bound)
-                            if (lane == kq && q_is_bound && gq == G_H) {
-                                if (r + 1.0 > 0.0) { double tt = fmax(l - lam_q, 0.0) / (r + 1.0); if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | t; } }
-                            } else if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
-                        } else {
-                            if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
-                            else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
-                        }
+                        // rigid row of the quadratic slack: 0 <= lambda <= w
+                        if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                        else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
                     } else {
                         if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
                         if (g2 == G_F) { sumLF += l; sumRF += r; } else if (g2 == G_S) { sumLS += l; sumRS += r; } else if (g2 == G_V) { sumLV += l; sumRV += r; }
@@ -789,9 +828,18 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                         }
                     }
                 }
-                if (lane == kq && !q_is_bound && gq == G_H && !inc_compl) {
+                if (lane == kq && !q_is_bound && gq == G_H) {
                     double tt = fmax(c.wH - lam_q, 0.0);
                     if (tt < t1) { t1 = tt; ev = (EV_CAPIN << 16) | (lane << 5); }
+                }
+                if (lane == kq && q_is_bound && gq == G_H) {
+                    // incoming slack bound of a penalised row: the row's own multiplier
+                    // w + q*xi - mu must stay >= 0 while xi rises with the step
+                    const double xi_now = L.lbH - viol, den = 1.0 - c.qH * zz;
+                    if (den > 0.0) {
+                        double tt = fmax(c.wH + c.qH * xi_now - lam_q, 0.0) / den;
+                        if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | R_HWP; }
+                    }
                 }
                 wave_argmin(t1, ev);
             }
@@ -808,8 +856,8 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             if (t2 <= t1) {
                 // full step: the incoming constraint becomes active
                 if (lane == kq) {
-                    if (!q_is_bound) set_code(L, tq, inc_compl ? 3 : 1);
-                    else if (gq == G_H) set_code(L, R_HWP, 1);      // compliant row turns rigid
+                    if (!q_is_bound) set_code(L, tq, 1);
+                    else if (gq == G_H) set_code(L, R_HWP, 1);      // penalised row turns rigid
                     else { int p = pivot_of(L, gq); set_code(L, p, 1); }
                 }
                 finished = true;
@@ -818,7 +866,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                 if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
                 else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
                 else if (ek == EV_DROPH) { if (lane == el) set_code(L, et, 0); finished = true; }
-                else if (ek == EV_CAPIN) { inc_compl = true; }
+                else if (ek == EV_CAPIN) { if (lane == el) set_code(L, R_HWP, 3); finished = true; }
                 else if (ek == EV_CAP) {
                     int fin = 0;
                     if (lane == el) {
@@ -1018,7 +1066,7 @@ struct StepOut { double out[EEPACC_OUT_N]; int status, iters; };
 // One ABMPC step for the wave's instance (ABO/RunOpt_ABMPC.m:193-329).  `code` carries the
 // working set between steps (already shifted by the caller).
 template <int MMAX>
-__device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const double* Hs, const StepIn& in,
+__device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, double* Hs, const StepIn& in,
                         unsigned long long& code, StepOut& so, double& s_pred, double& v_pred) {
     Lane L;
     L.lane = lane_id(); L.N = C.N;
@@ -1094,7 +1142,11 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const
     }
     L.a = L.sh = L.vh = L.am1 = 0.0;
     double grad_total = 0.0;
-    SolveStats st = solve_qp<MMAX>(L, c, M, Hs, C.tau, C.max_iter, grad_total);
+    // per-wave inverse of the effective Hessian: start from the step-invariant H^-1
+    he_load_base(Hs, C.Hinv, N, lane);
+    L.kmask = 0ull;
+    WSYNC();
+    SolveStats st = solve_qp<MMAX>(L, c, M, Hs, C.Hinv, C.tau, C.max_iter, grad_total);
     code = L.code;
     // recover z = Psi x + d (A7): predicted states
     s_pred = sf + L.sh; v_pred = vf + L.vh;
@@ -1104,11 +1156,16 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, const
         xiF = fmax(group_xi(L, c, G_F), L.lbF);
         xiS = fmax(group_xi(L, c, G_S), L.lbS);
         xiV = fmax(group_xi(L, c, G_V), L.lbV);
-        xiH = (code_of(L, R_HWP) == 3) ? (L.lamt[R_HWP] - c.wH) / c.qH : L.lbH;
+        xiH = (code_of(L, R_HWP) == 3) ? fmax(row_val(L, c, R_HWP, L.ba[R_HWP]), L.lbH) : L.lbH;
     }
     // 1/2 a'Ha + g'a with H a = -(grad_total - g0) - g0 ... : H a = -grad_total  => a'(g0 - grad/2)
+    // 1/2 a'Ha = 1/2 a'H_eff a - q/2 sum_K (n_k'a)^2 and H_eff a = -grad_total
     double part = (lane < N) ? L.a * (L.g0 - 0.5 * grad_total) : 0.0;
     part += C.w_f * xiF + C.w_s * xiS + C.w_v * xiV + c.wH * xiH + 0.5 * c.qH * xiH * xiH;
+    if (lane < N && code_of(L, R_HWP) == 3) {
+        const double na = row_val(L, c, R_HWP, L.ba[R_HWP]) + L.ba[R_HWP];      // n_k'a
+        part -= 0.5 * c.qH * na * na;
+    }
     const double cost = wave_sum(part);
     const double a0 = bcast(L.a, 0);
     double Fm, Fb, a_real;
@@ -1147,23 +1204,18 @@ __device__ __forceinline__ unsigned long long shift_codes(unsigned long long cod
     return code;
 }
 
-constexpr int kWavesPerBlock = 2;
+constexpr int kWavesPerBlock = 4;
 
-// LDS layout of a block: [Hinv N x N][HSs (N+1) x N][HSv (N+1) x N] shared, then one WaveMem per wave
-__host__ __device__ inline size_t table_doubles(int N) { return (size_t)N * N + 2 * (size_t)(N + 1) * N; }
-
-template <int MMAX>
-__device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, const double*& Hs) {
-    Hs = reinterpret_cast<const double*>(smem);
-    size_t off = (table_doubles(N) * sizeof(double) + 15) & ~(size_t)15;
-    return reinterpret_cast<WaveMem<MMAX>*>(smem + off) + (threadIdx.x >> 6);
+// LDS layout of a block: per wave [WaveMem][He: N x N doubles]
+__host__ __device__ inline size_t wave_bytes(size_t wm, int N) {
+    return ((wm + (size_t)N * N * sizeof(double)) + 15) & ~(size_t)15;
 }
 
-__device__ __forceinline__ void load_hinv(unsigned char* smem, const DevCfg& C) {
-    double* Hs = reinterpret_cast<double*>(smem);
-    const int n = (int)table_doubles(C.N);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) Hs[i] = C.Hinv[i];
-    __syncthreads();
+template <int MMAX>
+__device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, double*& He) {
+    unsigned char* base = smem + wave_bytes(sizeof(WaveMem<MMAX>), N) * (threadIdx.x >> 6);
+    He = reinterpret_cast<double*>(base + sizeof(WaveMem<MMAX>));
+    return reinterpret_cast<WaveMem<MMAX>*>(base);
 }
 
 // B2: one step for B instances.  state: per instance 64 x uint64 codes (instance-major).
@@ -1177,10 +1229,9 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
           int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
-    load_hinv(smem, C);
     const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (b >= B) return;
-    const double* Hs;
+    double* Hs;
     WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
     const int lane = lane_id();
     StepIn in{s[b], v[b], a_prev[b], t0[b], s_tv[b], v_tv[b], a_tv_prev[b]};
@@ -1212,10 +1263,9 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
             double* __restrict__ traj, int32_t* __restrict__ status, int32_t* __restrict__ iters_total) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
-    load_hinv(smem, C);
     const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (b >= B) return;
-    const double* Hs;
+    double* Hs;
     WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
     const int lane = lane_id();
     const double Ts = C.Tvec[0];
@@ -1306,11 +1356,13 @@ __global__ void k_postprocess(const DevCfg* __restrict__ Cp, int B, int n_steps,
 // host-side launchers used by eepacc_capi.cpp
 namespace eepacc {
 
-constexpr int kMMax = 64;
+// working-set capacity: rigid rows are linearly independent, so m <= N (+ terminal rows)
+constexpr int kMMaxSmall = 36;     // N <= 34
+constexpr int kMMaxLarge = 66;     // N <= 63
 
 size_t ab_smem_bytes(int N) {
-    size_t off = (table_doubles(N) * sizeof(double) + 15) & ~(size_t)15;
-    return off + sizeof(WaveMem<kMMax>) * kWavesPerBlock;
+    size_t wm = N <= kMMaxSmall - 2 ? sizeof(WaveMem<kMMaxSmall>) : sizeof(WaveMem<kMMaxLarge>);
+    return wave_bytes(wm, N) * kWavesPerBlock;
 }
 
 hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const double* v, const double* a_prev,
@@ -1318,9 +1370,14 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream) {
     const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMax>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                       ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
-                       s_pred, v_pred, status, iters);
+    if (N <= kMMaxSmall - 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMaxSmall>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                           ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
+                           s_pred, v_pred, status, iters);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMaxLarge>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                           ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
+                           s_pred, v_pred, status, iters);
     return hipGetLastError();
 }
 
@@ -1329,9 +1386,14 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int k_start, int n_s
                             double* carry, unsigned long long* codes, double* traj,
                             int32_t* status, int32_t* iters_total, hipStream_t stream) {
     const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMax>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                       ab_smem_bytes(N), stream, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes,
-                       traj, status, iters_total);
+    if (N <= kMMaxSmall - 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMaxSmall>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                           ab_smem_bytes(N), stream, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes,
+                           traj, status, iters_total);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMaxLarge>), dim3(blocks), dim3(64 * kWavesPerBlock),
+                           ab_smem_bytes(N), stream, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes,
+                           traj, status, iters_total);
     return hipGetLastError();
 }
 
@@ -1342,11 +1404,13 @@ hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double
 }
 
 hipError_t set_max_smem() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ab_step<kMMax>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_run_abmpc<kMMax>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_ab_step<kMMaxSmall>), reinterpret_cast<const void*>(&k_ab_step<kMMaxLarge>),
+                          reinterpret_cast<const void*>(&k_run_abmpc<kMMaxSmall>), reinterpret_cast<const void*>(&k_run_abmpc<kMMaxLarge>)};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace eepacc

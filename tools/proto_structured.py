@@ -220,9 +220,7 @@ class StructuredQP:
         if g is None:
             return r["n"], r["b"], 0.0
         G = self.p.groups[g]; st = self.gstate[g]
-        if G["q"] > 0:                      # Huber group: single row
-            if st["compl"]:
-                return r["n"], r["b"] - G["w"] / G["q"], 1.0 / G["q"]
+        if G["q"] > 0:                      # quadratic slack: in the working set only while xi = lb
             return r["n"], r["b"] + G["lb"], 0.0
         if st["P"]:
             pr = self.p.rows[st["pivot"]]
@@ -232,11 +230,23 @@ class StructuredQP:
     def g_eff(self):
         g = self.p.g.copy()
         for gk, st in self.gstate.items():
+            G = self.p.groups[gk]
             if st["P"]:
-                g += self.p.groups[gk]["w"] * self.p.rows[st["pivot"]]["n"]
+                g += G["w"] * self.p.rows[st["pivot"]]["n"]
+            if G["q"] > 0 and st["compl"]:
+                # penalty w*xi + q/2*xi^2 with xi = n'a - b folded into the objective
+                r = self.p.rows[G["rows"][0]]
+                g += (G["w"] - G["q"] * r["b"]) * r["n"]
         return g
 
     def factor(self):
+        Heff = self.p.H.copy()
+        for gk, st in self.gstate.items():
+            G = self.p.groups[gk]
+            if G["q"] > 0 and st["compl"]:
+                n = self.p.rows[G["rows"][0]]["n"]
+                Heff += G["q"] * np.outer(n, n)
+        self.Hinv = np.linalg.inv(Heff)
         m = len(self.W)
         if m == 0:
             self.C = np.zeros((0, self.N)); self.d = np.zeros(0); self.D = np.zeros(0)
@@ -283,8 +293,8 @@ class StructuredQP:
         G = self.p.groups[g]; st = self.gstate[g]
         if G["q"] > 0:
             if st["compl"]:
-                j = G["rows"][0]
-                return (self.lam[j] - G["w"]) / G["q"]
+                r = self.p.rows[G["rows"][0]]
+                return r["n"] @ a - r["b"]
             return G["lb"]
         if st["P"]:
             pr = self.p.rows[st["pivot"]]
@@ -313,6 +323,8 @@ class StructuredQP:
             g = r["grp"]
             if g is not None and self.gstate[g]["P"] and self.gstate[g]["pivot"] == j:
                 continue
+            if g is not None and self.p.groups[g]["q"] > 0 and self.gstate[g]["compl"]:
+                continue
             val = r["n"] @ a - r["b"]
             if g is not None:
                 val -= self.xi(g, a)
@@ -332,9 +344,6 @@ class StructuredQP:
         if q[0] == "row":
             j = q[1]
             r = self.p.rows[j]; g = r["grp"]
-            if g is not None and self.p.groups[g]["q"] > 0 and self.gstate[g]["compl"]:
-                G = self.p.groups[g]
-                return r["n"], r["b"] - G["w"] / G["q"], 1.0 / G["q"]
             if g is not None and self.p.groups[g]["q"] == 0 and self.gstate[g]["P"]:
                 pr = self.p.rows[self.gstate[g]["pivot"]]
                 return r["n"] - pr["n"], r["b"] - pr["b"], 0.0
@@ -398,26 +407,25 @@ class StructuredQP:
                     lam = self.lam[j]
                     if g is not None and p.groups[g]["q"] > 0:
                         G = p.groups[g]
-                        if self.gstate[g]["compl"]:
-                            # multiplier of the row itself = Lambda - mu must stay >= 0
-                            if q[0] == "bound" and q[1] == g:
-                                if r[i] + 1.0 > 0:
-                                    t = max(lam - lam_q, 0.0) / (r[i] + 1.0)
-                                    if t < t1: t1, ev = t, ("drop_h", j)
-                            elif r[i] > 0:
-                                t = lam / r[i]
-                                if t < t1: t1, ev = t, ("drop", j)
-                        else:
-                            if r[i] > 0:
-                                t = lam / r[i]
-                                if t < t1: t1, ev = t, ("drop", j)
-                            elif r[i] < 0:
-                                t = (G["w"] - lam) / (-r[i])
-                                if t < t1: t1, ev = t, ("compl", j)
+                        if r[i] > 0:
+                            t = lam / r[i]
+                            if t < t1: t1, ev = t, ("drop", j)
+                        elif r[i] < 0:
+                            t = (G["w"] - lam) / (-r[i])
+                            if t < t1: t1, ev = t, ("compl", j)
                     else:
                         if r[i] > 0:
                             t = lam / r[i]
                             if t < t1: t1, ev = t, ("drop", j)
+                if q[0] == "bound" and p.groups[q[1]]["q"] > 0:
+                    # incoming slack bound of a penalised row: the row's own multiplier
+                    # w + q*xi - mu must stay >= 0 (xi rises with the step as viol falls)
+                    G = p.groups[q[1]]
+                    xi_now = G["lb"] - viol
+                    den = 1.0 - G["q"] * zz
+                    if den > 0:
+                        t = max(G["w"] + G["q"] * xi_now - lam_q, 0.0) / den
+                        if t < t1: t1, ev = t, ("drop_h", q[1])
                 for g, st in self.gstate.items():
                     G = p.groups[g]
                     if G["q"] > 0:
@@ -458,9 +466,11 @@ class StructuredQP:
             return
         g = q[1]
         if self.p.groups[g]["q"] > 0:
-            # bound of a quadratic slack became active: the compliant row turns rigid
-            # (its multiplier Lambda - mu is recomputed from the working set)
+            # bound of a quadratic slack became active: the penalised row turns rigid
+            # (its multiplier w + q*lb - mu is recomputed from the working set)
             self.gstate[g]["compl"] = False
+            j = self.p.groups[g]["rows"][0]
+            self.W.append(j); self.lam[j] = max(self.p.groups[g]["w"] - lam_q, 0.0)
             return
         # bound of a P group became active: group -> Z, pivot becomes an ordinary row
         st = self.gstate[g]
@@ -478,20 +488,20 @@ class StructuredQP:
             self.W.remove(j); del self.lam[j]
             return False
         if kind == "compl":
-            g = p.rows[ev[1]]["grp"]; self.gstate[g]["compl"] = True
-            self.lam[ev[1]] = p.groups[g]["w"]
+            # multiplier reached the cap w: the slack leaves its bound, the row becomes a penalty
+            j = ev[1]; g = p.rows[j]["grp"]
+            self.W.remove(j); del self.lam[j]
+            self.gstate[g]["compl"] = True
             return False
         if kind == "drop_h":
             # the incoming bound of a quadratic slack takes over: the row leaves, xi sits on its bound
-            j = ev[1]; g = p.rows[j]["grp"]
-            self.W.remove(j); del self.lam[j]
-            self.gstate[g]["compl"] = False
+            self.gstate[ev[1]]["compl"] = False
             return True
         if kind == "cap_in":
-            # incoming Huber row reached lambda = w before becoming tight: its slack leaves the
-            # bound (xi_h > 0); the row keeps coming in, now as a compliant row
+            # incoming row reached lambda = w before becoming tight: its slack leaves the bound and
+            # the row turns into a penalty term of the objective; nothing is left to add
             self.gstate[ev[1]]["compl"] = True
-            return False
+            return True
         if kind == "cap":
             g = ev[1]; st = self.gstate[g]; G = p.groups[g]
             members = [j for j in self.W if p.rows[j]["grp"] == g]
@@ -551,6 +561,9 @@ def export_states(qp: StructuredQP):
         if s["P"]:
             r = p.rows[s["pivot"]]
             st[(r["name"], r["k"])] = 2
+        if p.groups[g]["q"] > 0 and s["compl"]:
+            r = p.rows[p.groups[g]["rows"][0]]
+            st[(r["name"], r["k"])] = 3
     return st
 
 
@@ -584,9 +597,10 @@ def warm_start(qp: StructuredQP, st, max_pass=16):
         j = index[key]; g = p.rows[j]["grp"]
         if g is not None and qp.gstate[g]["P"] and qp.gstate[g]["pivot"] == j:
             continue
-        qp.W.append(j)
         if code == 3 and g is not None and p.groups[g]["q"] > 0:
-            qp.gstate[g]["compl"] = True
+            qp.gstate[g]["compl"] = True          # penalty row: not part of the working set
+            continue
+        qp.W.append(j)
     # drop linearly dependent rows (e.g. amax & jmax patterns) by rank check
     for it in range(max_pass):
         qp.lam = {}
@@ -606,11 +620,8 @@ def warm_start(qp: StructuredQP, st, max_pass=16):
             g = p.rows[j]["grp"]; lam = qp.lam[j]
             if g is not None and p.groups[g]["q"] > 0:
                 G = p.groups[g]
-                if qp.gstate[g]["compl"]:
-                    if -lam > worst: worst, fix = -lam, ("drop", j)
-                else:
-                    if -lam > worst: worst, fix = -lam, ("drop", j)
-                    if lam - G["w"] > worst: worst, fix = lam - G["w"], ("compl", j)
+                if -lam > worst: worst, fix = -lam, ("drop", j)
+                if lam - G["w"] > worst: worst, fix = lam - G["w"], ("compl", j)
             elif -lam > worst:
                 worst, fix = -lam, ("drop", j)
         for g, s_ in qp.gstate.items():
@@ -627,11 +638,9 @@ def warm_start(qp: StructuredQP, st, max_pass=16):
                 g = p.rows[j]["grp"]; lam = qp.lam[j]
                 if g is not None and p.groups[g]["q"] > 0:
                     G = p.groups[g]
-                    if qp.gstate[g]["compl"]:
-                        if lam < -tol:
-                            qp.W.remove(j); qp.gstate[g]["compl"] = False
-                    elif lam < -tol: qp.W.remove(j)
-                    elif lam > G["w"] + tol: qp.gstate[g]["compl"] = True
+                    if lam < -tol: qp.W.remove(j)
+                    elif lam > G["w"] + tol:
+                        qp.W.remove(j); qp.gstate[g]["compl"] = True
                 elif lam < -tol:
                     qp.W.remove(j)
             for g, s_ in qp.gstate.items():
@@ -650,10 +659,8 @@ def warm_start(qp: StructuredQP, st, max_pass=16):
             bad = True
             if fix[0] == "drop":
                 qp.W.remove(fix[1])
-                gg = p.rows[fix[1]]["grp"]
-                if gg is not None and p.groups[gg]["q"] > 0:
-                    qp.gstate[gg]["compl"] = False
             elif fix[0] == "compl":
+                qp.W.remove(fix[1])
                 qp.gstate[p.rows[fix[1]]["grp"]]["compl"] = True
             else:
                 g = fix[1]; s_ = qp.gstate[g]
