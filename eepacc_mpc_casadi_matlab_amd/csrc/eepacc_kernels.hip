@@ -1220,7 +1220,7 @@ __device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, double*& He) {
 
 // B2: one step for B instances.  state: per instance 64 x uint64 codes (instance-major).
 template <int MMAX>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 2)
 k_ab_step(const DevCfg* __restrict__ Cp, int B,
           const double* __restrict__ s, const double* __restrict__ v, const double* __restrict__ a_prev,
           const double* __restrict__ t0, const double* __restrict__ s_tv, const double* __restrict__ v_tv,
@@ -1255,7 +1255,7 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
 // resumes from the carried per-instance state (carry [6][B]: s, v, Fm, Fb of the previous step,
 // previous lead speed, t_0; codes: shifted working set).
 template <int MMAX>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 2)
 k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
             const double* __restrict__ s0, const double* __restrict__ v0, const double* __restrict__ a_m1,
             const double* __restrict__ s_tv, const double* __restrict__ v_tv,
