@@ -18,7 +18,8 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const
 hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
-                            int32_t* status, int32_t* iters_total, hipStream_t stream);
+                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int num_cus,
+                            hipStream_t stream);
 hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
                               double* P, double* E, hipStream_t stream);
 hipError_t set_max_smem();
@@ -39,6 +40,9 @@ struct eepacc_handle {
     unsigned long long* d_codes = nullptr;   // [max_batch][64]
     int32_t* d_iters = nullptr;              // [max_batch]
     double* d_carry = nullptr;               // [6][B] closed-loop carry (see k_run_abmpc)
+    int* d_counter = nullptr;                // work counter of the closed-loop kernel
+    int* d_done = nullptr;                   // [max_batch] chunks finished per instance
+    int num_cus = 256;
     int last_B = 0;
     int k_done = 0;                          // closed-loop steps already run since the last reset
     int carry_B = 0;
@@ -183,6 +187,13 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMemset(h->d_iters, 0, (size_t)max_batch * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_carry, (size_t)max_batch * 6 * sizeof(double)));
     HIPCHK(hipMemset(h->d_carry, 0, (size_t)max_batch * 6 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_counter, sizeof(int)));
+    HIPCHK(hipMalloc(&h->d_done, sizeof(int) * (size_t)max_batch));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     HIPCHK(eepacc::set_max_smem());
     *out = h;
     return EEPACC_OK;
@@ -196,6 +207,8 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_codes) (void)hipFree(h->d_codes);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_carry) (void)hipFree(h->d_carry);
+    if (h->d_counter) (void)hipFree(h->d_counter);
+    if (h->d_done) (void)hipFree(h->d_done);
     delete h;
 }
 
@@ -235,7 +248,8 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");
     h->last_B = B;
     HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
-                                    h->d_carry, h->d_codes, traj, status, h->d_iters, (hipStream_t)stream));
+                                    h->d_carry, h->d_codes, traj, status, h->d_iters, h->d_counter, h->d_done, h->num_cus,
+                                    (hipStream_t)stream));
     h->k_done += n_steps; h->carry_B = B;
     return EEPACC_OK;
 }

@@ -11,6 +11,7 @@
 // method on the N x N acceleration block.  DESIGN.md has the derivation.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "eepacc_device.h"
 #include "../../include/eepacc.h"
 
@@ -22,6 +23,7 @@ constexpr double kInf = 1e300;
 constexpr double kTolViol = 1e-11;
 constexpr double kTolDual = 1e-12;
 constexpr int kSinglePasses = 8;
+constexpr int kChunkStepsDefault = 16;      // MPC steps per work unit of the closed-loop kernel
 
 // ----------------------------------------------------------------------------------------------
 // wave primitives
@@ -118,13 +120,13 @@ __device__ __forceinline__ double row_de(int t, int k) {
     return t == R_JMAX ? -1.0 : (t == R_JMIN ? 1.0 : 0.0);
 }
 
-template <int MMAX>
-struct WaveMem {                 // one per wave, in LDS (followed by the wave's N x N matrix He)
+template <int MMAX, int NS>
+struct WaveMem {                 // one per wave, in LDS (followed by the wave's NS x NS matrix He)
     double P[MMAX * (MMAX + 1) / 2];
-    double yv[64], av[64];
-    double shv[65], vhv[65];
-    double ub[65], sub[65], vub[65];          // images of a vector; also scratch of adjoint()
-    double ws[65], wv[65], wa[65];
+    double yv[NS], av[NS];
+    double shv[NS + 1], vhv[NS + 1];
+    double ub[NS + 1], sub[NS + 1], vub[NS + 1];     // images of a vector; also scratch of adjoint()
+    double ws[NS + 1], wv[NS + 1], wa[NS + 1];
     double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX];
     double lam[MMAX], sv[MMAX], rv[MMAX], colk[MMAX];
     int w_k[MMAX];
@@ -192,16 +194,18 @@ __device__ __forceinline__ void hom_traj(const Lane& L, double x, double& sh, do
 }
 
 // out_k = sum_i Hinv[i][k] * yv[i]   (Hinv symmetric, table in LDS, yv in LDS)
-__device__ __forceinline__ double hinv_mul(const double* __restrict__ Hs, const double* yv, int N, int lane) {
+template <int NS>
+__device__ __forceinline__ double hinv_mul(const double* Hs, const double* yv, int N, int lane) {
+    // He is stored NS x NS (zero padded) so that every load has an immediate offset
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const int k = lane < N ? lane : 0;
-    int i = 0;
-    for (; i + 4 <= N; i += 4) {
-        const double h0 = Hs[(i + 0) * N + k], h1 = Hs[(i + 1) * N + k], h2 = Hs[(i + 2) * N + k], h3 = Hs[(i + 3) * N + k];
-        const double y0 = yv[i], y1 = yv[i + 1], y2 = yv[i + 2], y3 = yv[i + 3];
-        a0 = fma(h0, y0, a0); a1 = fma(h1, y1, a1); a2 = fma(h2, y2, a2); a3 = fma(h3, y3, a3);
+    const double* col = Hs + (lane & (NS - 1));
+#pragma unroll
+    for (int i = 0; i < NS; i += 4) {
+        a0 = fma(col[(i + 0) * NS], yv[i + 0], a0);
+        a1 = fma(col[(i + 1) * NS], yv[i + 1], a1);
+        a2 = fma(col[(i + 2) * NS], yv[i + 2], a2);
+        a3 = fma(col[(i + 3) * NS], yv[i + 3], a3);
     }
-    for (; i < N; ++i) a0 = fma(Hs[i * N + k], yv[i], a0);
     return lane < N ? (a0 + a1) + (a2 + a3) : 0.0;
 }
 
@@ -219,6 +223,7 @@ __device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, do
 
 // adjoint of the condensing: given stage weights on (s_k, v_k, a_k) in LDS (ws, wv, wa, k = 0..N)
 // returns d/da_j of sum_k ws_k s_k + wv_k v_k + wa_k a_k  for lane j < N
+template <int NS>
 __device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const double* wv, const double* wa, double* tmp) {
     // suffix sums over stages k > j are prefix sums over the reversed stage order: lane r holds
     // stage N - r; the three running sums are written back in stage order through LDS (wa[65..])
@@ -228,11 +233,11 @@ __device__ __forceinline__ double adjoint(const Lane& L, const double* ws, const
     const double s = in ? ws[k] : 0.0, v = in ? wv[k] : 0.0;
     const double tk = in ? L.tau_rev : 0.0;
     const double WS = scan_excl(s), WV = scan_excl(v), WST = scan_excl(s * tk);
-    if (in) { tmp[k] = WS; tmp[65 + k] = WV; tmp[130 + k] = WST; }
+    if (in) { tmp[k] = WS; tmp[(NS + 1) + k] = WV; tmp[2 * (NS + 1) + k] = WST; }
     WSYNC();
     const int j = L.lane;
     double g = 0.0;
-    if (j < N) g = wa[j] + L.T * (tmp[65 + j] + tmp[130 + j] - (L.tau1 - 0.5 * L.T) * tmp[j]);
+    if (j < N) g = wa[j] + L.T * (tmp[(NS + 1) + j] + tmp[2 * (NS + 1) + j] - (L.tau1 - 0.5 * L.T) * tmp[j]);
     WSYNC();
     return g;
 }
@@ -244,37 +249,37 @@ struct SolveStats { int status, iters, events, m; };
 // The quadratic slack xi_h of stage k, once above its bound, is eliminated into the objective:
 // H_eff = H + q * sum_k n_k n_k'  (n_k: a-space normal of the headway-policy row).  He holds
 // H_eff^-1 for this wave; adding / removing one stage is a Sherman-Morrison rank-one update.
-template <int MMAX>
-__device__ __forceinline__ void he_rank1(const Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* He,
+template <int MMAX, int NS>
+__device__ __forceinline__ void he_rank1(const Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* He,
                                          const double* tauv, int k, bool add) {
     const int lane = L.lane, N = L.N;
     const double chwk = bcast(L.chw, k);
     const double nk = normal_at(L, k, 1.0, chwk, 0.0, 0.0, tauv[k]);
-    if (lane < N) M.yv[lane] = nk;
+    if (lane < NS) M.yv[lane] = nk;
     WSYNC();
-    const double y = hinv_mul(He, M.yv, N, lane);
+    const double y = hinv_mul<NS>(He, M.yv, N, lane);
     double sy, vy;
     hom_traj(L, y, sy, vy);
     const double ny = bcast(sy + chwk * vy, k);                 // n_k' y
     const double kappa = add ? c.qH / (1.0 + c.qH * ny) : -c.qH / (1.0 - c.qH * ny);
-    if (lane < N) M.ub[lane] = y;
+    if (lane < NS) M.ub[lane] = y;          // y is zero beyond N
     WSYNC();
-    if (lane < N) {
+    if (lane < NS) {
         const double yj = kappa * y;
-        int i = 0;
-        for (; i + 4 <= N; i += 4) {
-            const double h0 = He[(i + 0) * N + lane], h1 = He[(i + 1) * N + lane], h2 = He[(i + 2) * N + lane], h3 = He[(i + 3) * N + lane];
+        double* col = He + lane;
+#pragma unroll
+        for (int i = 0; i < NS; i += 4) {
+            const double h0 = col[(i + 0) * NS], h1 = col[(i + 1) * NS], h2 = col[(i + 2) * NS], h3 = col[(i + 3) * NS];
             const double y0 = M.ub[i], y1 = M.ub[i + 1], y2 = M.ub[i + 2], y3 = M.ub[i + 3];
-            He[(i + 0) * N + lane] = fma(-y0, yj, h0); He[(i + 1) * N + lane] = fma(-y1, yj, h1);
-            He[(i + 2) * N + lane] = fma(-y2, yj, h2); He[(i + 3) * N + lane] = fma(-y3, yj, h3);
+            col[(i + 0) * NS] = fma(-y0, yj, h0); col[(i + 1) * NS] = fma(-y1, yj, h1);
+            col[(i + 2) * NS] = fma(-y2, yj, h2); col[(i + 3) * NS] = fma(-y3, yj, h3);
         }
-        for (; i < N; ++i) He[i * N + lane] = fma(-M.ub[i], yj, He[i * N + lane]);
     }
     WSYNC();
 }
 
-template <int MMAX>
-__device__ __forceinline__ void he_sync(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* He, const double* tauv) {
+template <int MMAX, int NS>
+__device__ __forceinline__ void he_sync(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* He, const double* tauv) {
     const unsigned long long want = __ballot(L.lane < L.N && code_of(L, R_HWP) == 3);
     unsigned long long diff = want ^ L.kmask;
     while (diff) {
@@ -285,16 +290,20 @@ __device__ __forceinline__ void he_sync(Lane& L, const Cfg& c, WaveMem<MMAX>& M,
     L.kmask = want;
 }
 
+template <int NS>
 __device__ __forceinline__ void he_load_base(double* He, const double* __restrict__ base, int N, int lane) {
-    const int n2 = N * N;
-    for (int i = lane; i < n2; i += 64) He[i] = base[i];
+#pragma unroll 4
+    for (int e = lane; e < NS * NS; e += 64) {
+        const int i = e / NS, j = e % NS;
+        He[e] = (i < N && j < N) ? base[i * N + j] : 0.0;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
 // rebuild the working-set list + effective rows from the state codes, build S = C Hinv C' + D,
 // invert it in place (symmetric sweeps).  returns m (or -1 if S was numerically singular).
-template <int MMAX>
-__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* Hs, const double* tauv) {
+template <int MMAX, int NS>
+__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* Hs, const double* tauv) {
     const int lane = L.lane, N = L.N;
     he_sync(L, c, M, Hs, tauv);
     // count this lane's active rows
@@ -342,9 +351,9 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     for (int j = 0; j < m; ++j) {
         const int kj = M.w_k[j];
         double cj = normal_at(L, kj, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj]);
-        if (lane < N) M.yv[lane] = cj;
+        if (lane < NS) M.yv[lane] = cj;
         WSYNC();
-        double u = hinv_mul(Hs, M.yv, N, lane);
+        double u = hinv_mul<NS>(Hs, M.yv, N, lane);
         double su, vu;
         hom_traj(L, u, su, vu);
         if (lane < N) M.ub[lane] = u;
@@ -404,8 +413,8 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
 }
 
 // gradient-side vector: g_eff + (incoming multiplier) * c_q + C' lam   evaluated per lane
-template <int MMAX>
-__device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, WaveMem<MMAX>& M, int m, bool with_lam,
+template <int MMAX, int NS>
+__device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, int m, bool with_lam,
                                 double lam_q, int kq, double qal, double qbe, double qga, double qde) {
     const int lane = L.lane, N = L.N;
     // pivot rows act like working-set rows with multiplier w_g (own stage: plain stores)
@@ -443,13 +452,13 @@ __device__ __forceinline__ double gradient_side(const Lane& L, const Cfg& c, Wav
         if (kq > 0 && qde != 0.0) atomicAdd(&M.wa[kq - 1], lam_q * qde);
     }
     WSYNC();
-    double g = adjoint(L, M.ws, M.wv, M.wa, M.ub);
+    double g = adjoint<NS>(L, M.ws, M.wv, M.wa, M.ub);
     return (lane < N) ? g + L.g0 : 0.0;
 }
 
 // C x for the working-set rows (x given through LDS images x / sx / vx): result for lane i < m
-template <int MMAX>
-__device__ __forceinline__ double rows_dot_img(const WaveMem<MMAX>& M, int i, int N, const double* x,
+template <int MMAX, int NS>
+__device__ __forceinline__ double rows_dot_img(const WaveMem<MMAX, NS>& M, int i, int N, const double* x,
                                                const double* sx, const double* vx) {
     const int ki = M.w_k[i];
     double s = M.e_al[i] * sx[ki] + M.e_be[i] * vx[ki];
@@ -457,14 +466,14 @@ __device__ __forceinline__ double rows_dot_img(const WaveMem<MMAX>& M, int i, in
     if (ki > 0) s += M.e_de[i] * x[ki - 1];
     return s;
 }
-template <int MMAX>
-__device__ __forceinline__ double rows_dot(const WaveMem<MMAX>& M, int i, int N) {
+template <int MMAX, int NS>
+__device__ __forceinline__ double rows_dot(const WaveMem<MMAX, NS>& M, int i, int N) {
     return rows_dot_img(M, i, N, M.ub, M.sub, M.vub);
 }
 
 // lam = -P (d + C h (+ nothing else)); h given through ub/sub/vub
-template <int MMAX>
-__device__ __forceinline__ void solve_multipliers(WaveMem<MMAX>& M, int m, int lane, int N) {
+template <int MMAX, int NS>
+__device__ __forceinline__ void solve_multipliers(WaveMem<MMAX, NS>& M, int m, int lane, int N) {
     if (lane < m) M.sv[lane] = M.e_d[lane] + rows_dot(M, lane, N);
     WSYNC();
     if (lane < m) {
@@ -476,7 +485,7 @@ __device__ __forceinline__ void solve_multipliers(WaveMem<MMAX>& M, int m, int l
 }
 
 // scatter working-set vector x[pos] back to the owning (lane, type) registers
-template <int MMAX>
+template <int MMAX, int NS>
 __device__ __forceinline__ void scatter_to_types(const Lane& L, const double* x, double* out) {
     int pos = L.base;
 #pragma unroll
@@ -490,15 +499,15 @@ __device__ __forceinline__ void scatter_to_types(const Lane& L, const double* x,
 
 // primal point from the multipliers: a = -Hinv (g_eff + lam_q c_q + C' lam); also refreshes the
 // homogeneous trajectories and their LDS images (av/shv/vhv)
-template <int MMAX>
-__device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, int m,
+template <int MMAX, int NS>
+__device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, const double* Hs, int m,
                                         double lam_q, int kq, double qal, double qbe, double qga, double qde,
                                         double& grad_total) {
     double g = gradient_side(L, c, M, m, true, lam_q, kq, qal, qbe, qga, qde);
     grad_total = g;
-    if (L.lane < L.N) M.yv[L.lane] = g;
+    if (L.lane < NS) M.yv[L.lane] = g;
     WSYNC();
-    L.a = -hinv_mul(Hs, M.yv, L.N, L.lane);
+    L.a = -hinv_mul<NS>(Hs, M.yv, L.N, L.lane);
     hom_traj(L, L.a, L.sh, L.vh);
     L.am1 = dpp_zero<0x138, 0xf>(L.a);
     if (L.lane < L.N) M.av[L.lane] = L.a;
@@ -510,8 +519,8 @@ __device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, W
 // accuracy degrades with cond(S) (many active rows, stiff ORIG weights); the residual of the
 // working-set equations  C a - D lam = d  is evaluated exactly from the scans and fed back
 // through P until it is at rounding level.  Stationarity holds by construction of a.
-template <int MMAX>
-__device__ __forceinline__ void refine_primal(Lane& L, const Cfg& c, WaveMem<MMAX>& M, const double* Hs, int m,
+template <int MMAX, int NS>
+__device__ __forceinline__ void refine_primal(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, const double* Hs, int m,
                                               double lam_q, int kq, double qal, double qbe, double qga, double qde,
                                               double& grad_total, int max_rounds) {
     primal_from_multipliers(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total);
@@ -550,370 +559,367 @@ __device__ __forceinline__ double group_xi(const Lane& L, const Cfg& c, int g) {
 // ----------------------------------------------------------------------------------------------
 // the dual active-set solve.  On entry L.code holds the (warm) working set; on exit the optimal
 // one, L.a the accelerations, L.lamt the multipliers per (lane, type).
-template <int MMAX>
-__device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MMAX>& M, double* Hs, const double* Hbase,
+// repair of dual infeasibilities of a warm working set (multipliers in L.lamt).  The first passes
+// fix only the worst one (a single wrong row usually drags many multipliers negative; dropping
+// them all would throw the warm start away), later passes fix all of them at once.
+template <int MMAX, int NS>
+__device__ __forceinline__ int warm_repair(Lane& L, const Cfg& c, const WaveMem<MMAX, NS>& M, int m, bool single) {
+    const int lane = L.lane, N = L.N;
+    double lmax = 0.0;
+    if (lane < m) lmax = fabs(M.lam[lane]);
+    lmax = wave_max(lmax);
+    const double tol = kTolDual * (1.0 + lmax);
+    int changed = 0;
+    double sumF = 0.0, sumS = 0.0, sumV = 0.0;
+    double worst = tol; int fix = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        int cd = code_of(L, t);
+        if (cd != 1) continue;
+        int g2 = lane_group(L, t);
+        double l = L.lamt[t];
+        if (g2 == G_H) {
+            if (-l > tol) {
+                if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
+            } else if (l - c.wH > tol) {
+                if (!single) { set_code(L, t, 3); changed = 1; } else if (l - c.wH > worst) { worst = l - c.wH; fix = (EV_COMPL << 16) | (lane << 5) | t; }
+            }
+        } else {
+            if (-l > tol) {
+                if (!single) { set_code(L, t, 0); changed = 1; l = 0.0; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
+            }
+            if (g2 == G_F) sumF += l; else if (g2 == G_S) sumS += l; else if (g2 == G_V) sumV += l;
+        }
+    }
+    // group margins (bound multiplier in Z, pivot multiplier in P)
+    int capg = 0;
+    if (lane < N) {
+#pragma unroll
+        for (int g2 = G_F; g2 <= G_V; ++g2) {
+            double sum = g2 == G_F ? sumF : (g2 == G_S ? sumS : sumV);
+            double w = group_w(c, g2);
+            double viol = sum - w;
+            if (viol > tol * (1.0 + w)) {
+                if (single) { if (viol > worst) { worst = viol; fix = (EV_CAP << 16) | (lane << 5) | g2; } }
+                else if (!changed && !capg) capg = g2;
+            }
+        }
+    }
+    int el = -1, et = capg;
+    if (single) {
+        wave_argmax(worst, fix);
+        if (fix != 0x7fffffff) {
+            changed = 1;
+            const int ek = fix >> 16;
+            el = (fix >> 5) & 63; et = fix & 31;
+            if (lane == el) {
+                if (ek == EV_DROP) { set_code(L, et, 0); el = -1; }
+                else if (ek == EV_COMPL) { set_code(L, et, 3); el = -1; }
+            }
+            if (ek != EV_CAP) el = -1;
+        } else el = -1;
+    } else if (capg) { el = lane; changed = 1; }
+    if (lane == el) {          // group cap violated: make the member with the largest multiplier the pivot
+        int p = pivot_of(L, et);
+        if (p >= 0) set_code(L, p, 0);
+        int bestt = -1; double bl = -1e300;
+#pragma unroll
+        for (int t = R_AMAX; t <= R_VINC; ++t)
+            if (group_of(t) == et && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
+        if (bestt >= 0) set_code(L, bestt, 2);
+    }
+    return __any(changed);
+}
+
+// most violated inactive row / slack bound: returns lane*32 + code (code: row type, or 16+group for
+// the bound of a slack) or -1; best = its scaled violation
+__device__ __forceinline__ int find_violation(const Lane& L, const Cfg& c, double tolv, double& best) {
+    const int lane = L.lane, N = L.N;
+    double xiF = 0, xiS = 0, xiV = 0;
+    if (lane < N) { xiF = group_xi(L, c, G_F); xiS = group_xi(L, c, G_S); xiV = group_xi(L, c, G_V); }
+    double myb = tolv; int myp = -1;
+#pragma unroll
+    for (int t = 0; t < kNumRowTypes; ++t) {
+        if (!((L.valid >> t) & 1u) || ((L.ign >> t) & 1u)) continue;
+        if (code_of(L, t) != 0) continue;
+        int g2 = lane_group(L, t);
+        double val = row_val(L, c, t, L.ba[t]);
+        val -= (g2 == G_F) ? xiF : (g2 == G_S ? xiS : (g2 == G_V ? xiV : (g2 == G_H ? L.lbH : 0.0)));
+        double sc = val / (1.0 + fabs(L.ba[t]));
+        if (sc > myb) { myb = sc; myp = t; }
+    }
+    if (lane < N) {
+        if (pivot_of(L, G_F) >= 0 && !((L.ign >> (16 + G_F)) & 1u) && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 16 + G_F; }
+        if (pivot_of(L, G_S) >= 0 && !((L.ign >> (16 + G_S)) & 1u) && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 16 + G_S; }
+        if (pivot_of(L, G_V) >= 0 && !((L.ign >> (16 + G_V)) & 1u) && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
+        // penalised quadratic slack: xi_h = n'a - b must stay above its bound
+        if (code_of(L, R_HWP) == 3 && !((L.ign >> (16 + G_H)) & 1u)) {
+            double xih = row_val(L, c, R_HWP, L.ba[R_HWP]);
+            if (L.lbH - xih > myb) { myb = L.lbH - xih; myp = 16 + G_H; }
+        }
+    }
+    best = myb;
+    int bp = (myp < 0) ? 0x7fffffff : (lane * 32 + myp);
+    wave_argmax(best, bp);
+    return bp == 0x7fffffff ? -1 : bp;
+}
+
+struct Incoming { int kq, qcode, tq, gq; bool is_bound; double al, be, ga, de, d; };
+
+// effective a-space row of the incoming constraint for the current group states (lane kq computes,
+// everyone receives)
+__device__ __forceinline__ void incoming_row(const Lane& L, const Cfg& c, Incoming& q) {
+    double qal = 0, qbe = 0, qga = 0, qde = 0, qd = 0;
+    const int lane = L.lane;
+    if (lane == q.kq) {
+        if (!q.is_bound) {
+            const int tq = q.tq;
+            qal = row_al(tq); qbe = row_be(tq, c.tau_min, L.chw); qga = row_ga(tq); qde = row_de(tq, lane);
+            double bq = 0.0;
+#pragma unroll
+            for (int u = 0; u < kNumRowTypes; ++u) if (u == tq) bq = L.ba[u];
+            qd = bq;
+            if (q.gq == G_H) {
+                qd += L.lbH;
+            } else if (q.gq != G_NONE) {
+                int p = pivot_of(L, q.gq);
+                if (p >= 0) {
+                    double pba = 0.0;
+#pragma unroll
+                    for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+                    qal -= row_al(p); qbe -= row_be(p, c.tau_min, L.chw); qga -= row_ga(p); qde -= row_de(p, lane);
+                    qd -= pba;
+                } else qd += group_lb(L, q.gq);
+            }
+        } else if (q.gq == G_H) {
+            qal = -row_al(R_HWP); qbe = -row_be(R_HWP, c.tau_min, L.chw);
+            qd = -(L.ba[R_HWP] + L.lbH);
+        } else {
+            int p = pivot_of(L, q.gq);
+            double pba = 0.0;
+#pragma unroll
+            for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
+            qal = -row_al(p); qbe = -row_be(p, c.tau_min, L.chw); qga = -row_ga(p); qde = -row_de(p, lane);
+            qd = -(pba + group_lb(L, q.gq));
+        }
+    }
+    q.al = bcast(qal, q.kq); q.be = bcast(qbe, q.kq); q.ga = bcast(qga, q.kq); q.de = bcast(qde, q.kq);
+    q.d = bcast(qd, q.kq);
+}
+
+// ----------------------------------------------------------------------------------------------
+// the dual active-set solve.  On entry L.code holds the (warm) working set; on exit the optimal
+// one, L.a the accelerations, L.lamt the multipliers per (lane, type).  One loop, one working-set
+// change per pass: [rebuild + factor] -> [multipliers] -> [primal + refinement] -> either repair the
+// warm start, or pick the next violated constraint / continue the current one and take the step.
+template <int MMAX, int NS>
+__device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* Hs, const double* Hbase,
                                const double* tauv, int max_iter, double& grad_total) {
     const int lane = L.lane, N = L.N;
     SolveStats st{0, 0, 0, 0};
     int m = 0;
-    // ---- warm start: make the shifted working set dual feasible -------------------------
-    {
-        bool ok = false;
-        for (int pass = 0; pass < kSinglePasses + 6 && !ok; ++pass) {
-            m = rebuild_and_factor(L, c, M, Hs, tauv);
-            if (m < 0) break;
-            if (m == 0) { ok = true; break; }
-            // h = Hinv g_eff
-            double g = gradient_side(L, c, M, 0, false, 0.0, 0, 0, 0, 0, 0);
-            if (lane < N) M.yv[lane] = g;
+    bool warm = true, have_q = false;
+    int pass = 0;
+    double lam_q = 0.0, best = 0.0;
+    Incoming q{0, 0, 0, 0, false, 0, 0, 0, 0, 0};
+    for (;;) {
+        m = rebuild_and_factor(L, c, M, Hs, tauv);
+        if (m < 0) {
+            if (!warm) { st.status = 2; break; }
+            L.code = 0ull;                 // unusable warm start: cold start
+            he_load_base<NS>(Hs, Hbase, N, lane);
+            L.kmask = 0ull;
             WSYNC();
-            double h = hinv_mul(Hs, M.yv, N, lane);
+            warm = false;
+            continue;
+        }
+        if (have_q) incoming_row(L, c, q);
+        if (m > 0) {
+            // multipliers of the working set for the current incoming multiplier
+            double g = gradient_side(L, c, M, 0, false, lam_q, q.kq, q.al, q.be, q.ga, q.de);
+            if (lane < NS) M.yv[lane] = g;
+            WSYNC();
+            double h = hinv_mul<NS>(Hs, M.yv, N, lane);
             double shh, vhh;
             hom_traj(L, h, shh, vhh);
             if (lane < N) M.ub[lane] = h;
             if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
             WSYNC();
             solve_multipliers(M, m, lane, N);
-            scatter_to_types<MMAX>(L, M.lam, L.lamt);
-            // repair of dual infeasibilities.  The first passes fix only the worst one (a single
-            // wrong row usually drags many multipliers negative; dropping them all would throw the
-            // warm start away), later passes fix all of them at once.
-            const bool single = pass < kSinglePasses;
-            double lmax = 0.0;
-            if (lane < m) lmax = fabs(M.lam[lane]);
-            lmax = wave_max(lmax);
-            const double tol = kTolDual * (1.0 + lmax);
-            int changed = 0;
-            double sumF = 0.0, sumS = 0.0, sumV = 0.0;
-            double worst = tol; int fix = 0x7fffffff;
+        }
+        refine_primal(L, c, M, Hs, m, lam_q, q.kq, q.al, q.be, q.ga, q.de, grad_total, 4);
+        if (warm) {
+            if (m > 0) {
+                scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
+                if (warm_repair(L, c, M, m, pass < kSinglePasses)) {
+                    if (++pass >= kSinglePasses + 6) {
+                        L.code = 0ull;
+                        he_load_base<NS>(Hs, Hbase, N, lane);
+                        L.kmask = 0ull;
+                        WSYNC();
+                        warm = false;
+                    }
+                    continue;
+                }
+            }
+            warm = false;
+        }
+        if (!have_q) {
+            // Anti-cycling: rounding noise of the order of (largest multiplier) x eps can flip rows in
+            // and out at the tightest tolerance (seen with the ORIG weights, w_f = 1e7); the tolerance
+            // is relaxed decade by decade if the iteration count shows that this is happening (never
+            // beyond 1e-8, scaled by 1+|b|).
+            const int relax_every = 3 * N + 30;
+            const double tolv = kTolViol * (st.iters < relax_every ? 1.0 : (st.iters < 2 * relax_every ? 10.0 : (st.iters < 3 * relax_every ? 100.0 : 1000.0)));
+            const int bp = find_violation(L, c, tolv, best);
+            if (bp < 0) break;
+            if (++st.iters > max_iter) { st.status = 2; break; }
+            q.kq = bp >> 5; q.qcode = bp & 31;
+            q.is_bound = q.qcode >= 16;
+            q.tq = q.is_bound ? 0 : q.qcode;
+            q.gq = q.is_bound ? (q.qcode - 16) : ((q.kq == N) ? G_NONE : group_of(q.qcode));
+            have_q = true; lam_q = 0.0;
+            incoming_row(L, c, q);
+        }
+        if (++st.events > 40 * max_iter) { st.status = 2; break; }
+        const int kq = q.kq;
+        double viol = q.al * M.shv[kq] + q.be * M.vhv[kq] - q.d;
+        if (kq < N) viol += q.ga * M.av[kq];
+        if (kq > 0) viol += q.de * M.av[kq - 1];
+        // u = He c_q and its trajectories
+        double cj = normal_at(L, kq, q.al, q.be, q.ga, q.de, tauv[kq]);
+        if (lane < NS) M.yv[lane] = cj;
+        WSYNC();
+        double u = hinv_mul<NS>(Hs, M.yv, N, lane);
+        double su, vu;
+        hom_traj(L, u, su, vu);
+        if (lane < N) M.ub[lane] = u;
+        if (lane <= N) { M.sub[lane] = su; M.vub[lane] = vu; }
+        WSYNC();
+        double cu = q.al * M.sub[kq] + q.be * M.vub[kq];
+        if (kq < N) cu += q.ga * M.ub[kq];
+        if (kq > 0) cu += q.de * M.ub[kq - 1];
+        double sr = 0.0;
+        if (m > 0) {
+            if (lane < m) M.sv[lane] = rows_dot(M, lane, N);
+            WSYNC();
+            double r = 0.0;
+            if (lane < m) {
+                for (int j = 0; j < m; ++j) r = fma(M.P[pidx(lane, j)], M.sv[j], r);
+                M.rv[lane] = r;
+                sr = M.sv[lane] * r;
+            }
+            WSYNC();
+            sr = wave_sum(sr);
+        }
+        const double zz = cu - sr;
+        double t2 = (zz > 1e-8 * cu) ? viol / zz : kInf;
+        if (viol <= 0.0) t2 = 0.0;
+        // blocking events, evaluated per (lane, type)
+        scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
+        scatter_to_types<MMAX, NS>(L, M.rv, L.rt);
+        double t1 = kInf; int ev = 0x7fffffff;
+        {
+            double sumLF = 0, sumLS = 0, sumLV = 0, sumRF = 0, sumRS = 0, sumRV = 0;
 #pragma unroll
             for (int t = 0; t < kNumRowTypes; ++t) {
                 int cd = code_of(L, t);
                 if (cd != 1) continue;
                 int g2 = lane_group(L, t);
-                double l = L.lamt[t];
+                double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
                 if (g2 == G_H) {
-                    if (-l > tol) {
-                        if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
-                    } else if (l - c.wH > tol) {
-                        if (!single) { set_code(L, t, 3); changed = 1; } else if (l - c.wH > worst) { worst = l - c.wH; fix = (EV_COMPL << 16) | (lane << 5) | t; }
-                    }
+                    // rigid row of the quadratic slack: 0 <= lambda <= w
+                    if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                    else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
                 } else {
-                    if (-l > tol) {
-                        if (!single) { set_code(L, t, 0); changed = 1; l = 0.0; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
-                    }
-                    if (g2 == G_F) sumF += l; else if (g2 == G_S) sumS += l; else if (g2 == G_V) sumV += l;
+                    if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                    if (g2 == G_F) { sumLF += l; sumRF += r; } else if (g2 == G_S) { sumLS += l; sumRS += r; } else if (g2 == G_V) { sumLV += l; sumRV += r; }
                 }
             }
-            // group margins (bound multiplier in Z, pivot multiplier in P)
             if (lane < N) {
 #pragma unroll
                 for (int g2 = G_F; g2 <= G_V; ++g2) {
-                    double sum = g2 == G_F ? sumF : (g2 == G_S ? sumS : sumV);
-                    double w = group_w(c, g2);
-                    double viol = sum - w;
-                    if (viol > tol * (1.0 + w)) {
-                        if (single) { if (viol > worst) { worst = viol; fix = (EV_CAP << 16) | (lane << 5) | g2; } }
-                        else if (!changed) {
-                            changed = 1;
-                            int p = pivot_of(L, g2);
-                            if (p >= 0) set_code(L, p, 0);
-                            int bestt = -1; double bl = -1e300;
-#pragma unroll
-                            for (int t = R_AMAX; t <= R_VINC; ++t)
-                                if (group_of(t) == g2 && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
-                            if (bestt >= 0) set_code(L, bestt, 2);
-                        }
+                    double sl = g2 == G_F ? sumLF : (g2 == G_S ? sumLS : sumLV);
+                    double srr = g2 == G_F ? sumRF : (g2 == G_S ? sumRS : sumRV);
+                    double rate = -srr, margin = group_w(c, g2) - sl;
+                    if (lane == kq && q.gq == g2) { rate += 1.0; margin -= lam_q; }
+                    if (rate > 0.0) {
+                        double tt = fmax(margin, 0.0) / rate;
+                        if (tt < t1) { t1 = tt; ev = (EV_CAP << 16) | (lane << 5) | g2; }
                     }
                 }
             }
-            if (single) {
-                wave_argmax(worst, fix);
-                if (fix != 0x7fffffff) {
-                    changed = 1;
-                    const int ek = fix >> 16, el = (fix >> 5) & 63, et = fix & 31;
-                    if (lane == el) {
-                        if (ek == EV_DROP) set_code(L, et, 0);
-                        else if (ek == EV_COMPL) set_code(L, et, 3);
-                        else {
-                            int p = pivot_of(L, et);
-                            if (p >= 0) set_code(L, p, 0);
-                            int bestt = -1; double bl = -1e300;
-#pragma unroll
-                            for (int t = R_AMAX; t <= R_VINC; ++t)
-                                if (group_of(t) == et && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
-                            if (bestt >= 0) set_code(L, bestt, 2);
-                        }
-                    }
+            if (lane == kq && !q.is_bound && q.gq == G_H) {
+                double tt = fmax(c.wH - lam_q, 0.0);
+                if (tt < t1) { t1 = tt; ev = (EV_CAPIN << 16) | (lane << 5); }
+            }
+            if (lane == kq && q.is_bound && q.gq == G_H) {
+                // incoming slack bound of a penalised row: the row's own multiplier
+                // w + q*xi - mu must stay >= 0 while xi rises with the step
+                const double xi_now = L.lbH - viol, den = 1.0 - c.qH * zz;
+                if (den > 0.0) {
+                    double tt = fmax(c.wH + c.qH * xi_now - lam_q, 0.0) / den;
+                    if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | R_HWP; }
                 }
             }
-            if (!__any(changed)) ok = true;
+            wave_argmin(t1, ev);
         }
-        if (!ok) {
-            L.code = 0ull;           // cold start
-            he_load_base(Hs, Hbase, N, lane);
-            L.kmask = 0ull;
-            WSYNC();
-            m = rebuild_and_factor(L, c, M, Hs, tauv);
+        const double tstep = fmin(t1, t2);
+        if (!(tstep < 1e299)) {
+            // the incoming normal lies in the span of the working set and nothing can be dropped.
+            // With a real violation the QP is infeasible; with a rounding-level one the row is a
+            // duplicate of active rows (e.g. a_k pinned by an acceleration AND a jerk limit): mark it
+            // as ignored for this solve.
+            if (best < 1e-7) { if (lane == kq) L.ign |= (1u << q.qcode); have_q = false; lam_q = 0.0; continue; }
+            st.status = 1; break;
         }
-    }
-    // ---- main loop -------------------------------------------------------------------------
-    const double* none = nullptr; (void)none;
-    for (;;) {
-        refine_primal(L, c, M, Hs, m, 0.0, 0, 0, 0, 0, 0, grad_total, 3);
-        // most violated inactive row / group bound.  Anti-cycling: rounding noise of the order of
-        // (largest multiplier) x eps can flip rows in and out at the tightest tolerance (seen with
-        // the ORIG weights, w_f = 1e7); the tolerance is relaxed decade by decade if the iteration
-        // count shows that this is happening (never beyond 1e-8, scaled by 1+|b|).
-        const int relax_every = 3 * N + 30;
-        const double tolv = kTolViol * (st.iters < relax_every ? 1.0 : (st.iters < 2 * relax_every ? 10.0 : (st.iters < 3 * relax_every ? 100.0 : 1000.0)));
-        double best = tolv; int bp = -1;
-        {
-            double xiF = 0, xiS = 0, xiV = 0;
-            if (lane < N) { xiF = group_xi(L, c, G_F); xiS = group_xi(L, c, G_S); xiV = group_xi(L, c, G_V); }
-            double myb = tolv; int myp = -1;
-#pragma unroll
-            for (int t = 0; t < kNumRowTypes; ++t) {
-                if (!((L.valid >> t) & 1u) || ((L.ign >> t) & 1u)) continue;
-                if (code_of(L, t) != 0) continue;
-                int g2 = lane_group(L, t);
-                double val = row_val(L, c, t, L.ba[t]);
-                val -= (g2 == G_F) ? xiF : (g2 == G_S ? xiS : (g2 == G_V ? xiV : (g2 == G_H ? L.lbH : 0.0)));
-                double sc = val / (1.0 + fabs(L.ba[t]));
-                if (sc > myb) { myb = sc; myp = t; }
-            }
-            if (lane < N) {
-                if (pivot_of(L, G_F) >= 0 && !((L.ign >> (16 + G_F)) & 1u) && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 16 + G_F; }
-                if (pivot_of(L, G_S) >= 0 && !((L.ign >> (16 + G_S)) & 1u) && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 16 + G_S; }
-                if (pivot_of(L, G_V) >= 0 && !((L.ign >> (16 + G_V)) & 1u) && L.lbV - xiV > myb) { myb = L.lbV - xiV; myp = 16 + G_V; }
-                // quadratic slack of a compliant row: xi_h = (Lambda - w)/q must stay above its bound
-                if (code_of(L, R_HWP) == 3 && !((L.ign >> (16 + G_H)) & 1u)) {
-                    double xih = row_val(L, c, R_HWP, L.ba[R_HWP]);
-                    if (L.lbH - xih > myb) { myb = L.lbH - xih; myp = 16 + G_H; }
-                }
-            }
-            best = myb; bp = (myp < 0) ? 0x7fffffff : (lane * 32 + myp);
-            wave_argmax(best, bp);
-            if (bp == 0x7fffffff) bp = -1;
-        }
-        if (bp < 0) break;
-        if (++st.iters > max_iter) { st.status = 2; break; }
-        const int kq = bp >> 5, qcode = bp & 31;
-        const bool q_is_bound = qcode >= 16;
-        const int tq = q_is_bound ? -1 : qcode;
-        const int gq = q_is_bound ? (qcode - 16) : ((kq == N) ? G_NONE : group_of(qcode));
-        double lam_q = 0.0;
+        lam_q += tstep;
         bool finished = false;
-        bool first_pass = true;
-        while (!finished) {
-            if (++st.events > 40 * max_iter) { st.status = 2; finished = true; break; }
-            // effective incoming row (computed on lane kq, broadcast)
-            double qal = 0, qbe = 0, qga = 0, qde = 0, qd = 0;
+        if (t2 <= t1) {
+            // full step: the incoming constraint becomes active
             if (lane == kq) {
-                if (!q_is_bound) {
-                    qal = row_al(tq); qbe = row_be(tq, c.tau_min, L.chw); qga = row_ga(tq); qde = row_de(tq, lane);
-                    double bq = 0.0;
-#pragma unroll
-                    for (int u = 0; u < kNumRowTypes; ++u) if (u == tq) bq = L.ba[u];
-                    qd = bq;
-                    if (gq == G_H) {
-                        qd += L.lbH;
-                    } else if (gq != G_NONE) {
-                        int p = pivot_of(L, gq);
-                        if (p >= 0) {
-                            double pba = 0.0;
-#pragma unroll
-                            for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
-                            qal -= row_al(p); qbe -= row_be(p, c.tau_min, L.chw); qga -= row_ga(p); qde -= row_de(p, lane);
-                            qd -= pba;
-                        } else qd += group_lb(L, gq);
-                    }
-                } else if (gq == G_H) {
-                    qal = -row_al(R_HWP); qbe = -row_be(R_HWP, c.tau_min, L.chw);
-                    qd = -(L.ba[R_HWP] + L.lbH);
-                } else {
-                    int p = pivot_of(L, gq);
-                    double pba = 0.0;
-#pragma unroll
-                    for (int u = R_AMAX; u <= R_VINC; ++u) if (u == p) pba = L.ba[u];
-                    qal = -row_al(p); qbe = -row_be(p, c.tau_min, L.chw); qga = -row_ga(p); qde = -row_de(p, lane);
-                    qd = -(pba + group_lb(L, gq));
-                }
+                if (!q.is_bound) set_code(L, q.tq, 1);
+                else if (q.gq == G_H) set_code(L, R_HWP, 1);      // penalised row turns rigid
+                else { int p = pivot_of(L, q.gq); set_code(L, p, 1); }
             }
-            qal = bcast(qal, kq); qbe = bcast(qbe, kq); qga = bcast(qga, kq); qde = bcast(qde, kq);
-            qd = bcast(qd, kq);
-            // multipliers of the working set for the current incoming multiplier (the first pass
-            // of an iteration starts from the state the loop head has just computed)
-            if (!first_pass) {
-            m = rebuild_and_factor(L, c, M, Hs, tauv);
-            if (m < 0) { st.status = 2; finished = true; break; }
-            {
-                double g = gradient_side(L, c, M, 0, false, lam_q, kq, qal, qbe, qga, qde);
-                if (lane < N) M.yv[lane] = g;
-                WSYNC();
-                double h = hinv_mul(Hs, M.yv, N, lane);
-                double shh, vhh;
-                hom_traj(L, h, shh, vhh);
-                if (lane < N) M.ub[lane] = h;
-                if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
-                WSYNC();
-                if (m > 0) solve_multipliers(M, m, lane, N);
-            }
-            refine_primal(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total, 3);
-            }
-            first_pass = false;
-            double viol = qal * M.shv[kq] + qbe * M.vhv[kq] - qd;
-            if (kq < N) viol += qga * M.av[kq];
-            if (kq > 0) viol += qde * M.av[kq - 1];
-            // u = Hinv c_q and its trajectories
-            double cj = normal_at(L, kq, qal, qbe, qga, qde, tauv[kq]);
-            if (lane < N) M.yv[lane] = cj;
-            WSYNC();
-            double u = hinv_mul(Hs, M.yv, N, lane);
-            double su, vu;
-            hom_traj(L, u, su, vu);
-            if (lane < N) M.ub[lane] = u;
-            if (lane <= N) { M.sub[lane] = su; M.vub[lane] = vu; }
-            WSYNC();
-            double cu = qal * M.sub[kq] + qbe * M.vub[kq];
-            if (kq < N) cu += qga * M.ub[kq];
-            if (kq > 0) cu += qde * M.ub[kq - 1];
-            double sr = 0.0;
-            if (m > 0) {
-                if (lane < m) M.sv[lane] = rows_dot(M, lane, N);
-                WSYNC();
-                double r = 0.0;
-                if (lane < m) {
-                    for (int j = 0; j < m; ++j) r = fma(M.P[pidx(lane, j)], M.sv[j], r);
-                    M.rv[lane] = r;
-                    sr = M.sv[lane] * r;
-                }
-                WSYNC();
-                sr = wave_sum(sr);
-            }
-            const double zz = cu - sr;
-            double t2 = (zz > 1e-8 * cu) ? viol / zz : kInf;
-            if (viol <= 0.0) t2 = 0.0;
-            // blocking events, evaluated per (lane, type)
-            scatter_to_types<MMAX>(L, M.lam, L.lamt);
-            scatter_to_types<MMAX>(L, M.rv, L.rt);
-            double t1 = kInf; int ev = 0x7fffffff;
-            {
-                double sumLF = 0, sumLS = 0, sumLV = 0, sumRF = 0, sumRS = 0, sumRV = 0;
+            finished = true;
+        } else {
+            const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
+            if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
+            else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
+            else if (ek == EV_DROPH) { if (lane == el) set_code(L, et, 0); finished = true; }
+            else if (ek == EV_CAPIN) { if (lane == el) set_code(L, R_HWP, 3); finished = true; }
+            else if (ek == EV_CAP) {
+                int fin = 0;
+                if (lane == el) {
+                    const int g2 = et;
+                    // members (code 1) of the group with their multipliers after the step
+                    int bestm = -1; double bl = -1e300;
 #pragma unroll
-                for (int t = 0; t < kNumRowTypes; ++t) {
-                    int cd = code_of(L, t);
-                    if (cd != 1) continue;
-                    int g2 = lane_group(L, t);
-                    double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
-                    if (g2 == G_H) {
-                        // rigid row of the quadratic slack: 0 <= lambda <= w
-                        if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
-                        else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
-                    } else {
-                        if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
-                        if (g2 == G_F) { sumLF += l; sumRF += r; } else if (g2 == G_S) { sumLS += l; sumRS += r; } else if (g2 == G_V) { sumLV += l; sumRV += r; }
-                    }
-                }
-                if (lane < N) {
-#pragma unroll
-                    for (int g2 = G_F; g2 <= G_V; ++g2) {
-                        double sl = g2 == G_F ? sumLF : (g2 == G_S ? sumLS : sumLV);
-                        double srr = g2 == G_F ? sumRF : (g2 == G_S ? sumRS : sumRV);
-                        double rate = -srr, margin = group_w(c, g2) - sl;
-                        if (lane == kq && gq == g2) { rate += 1.0; margin -= lam_q; }
-                        if (rate > 0.0) {
-                            double tt = fmax(margin, 0.0) / rate;
-                            if (tt < t1) { t1 = tt; ev = (EV_CAP << 16) | (lane << 5) | g2; }
+                    for (int t = R_AMAX; t <= R_VINC; ++t)
+                        if (group_of(t) == g2 && code_of(L, t) == 1) {
+                            double l = L.lamt[t] - tstep * ((m > 0) ? L.rt[t] : 0.0);
+                            if (l > bl) { bl = l; bestm = t; }
                         }
+                    const int p = pivot_of(L, g2);
+                    const bool q_row_here = (kq == el) && !q.is_bound && q.gq == g2;
+                    const bool q_bound_here = (kq == el) && q.is_bound && q.gq == g2;
+                    if (p < 0) {                       // Z -> P
+                        if (bestm < 0) { set_code(L, q.tq, 2); fin = 1; }
+                        else set_code(L, bestm, 2);
+                    } else {                           // pivot multiplier reached zero
+                        set_code(L, p, 0);
+                        if (bestm >= 0) set_code(L, bestm, 2);
+                        else if (q_row_here) { set_code(L, q.tq, 2); fin = 1; }
+                        else if (q_bound_here) { fin = 1; }
                     }
                 }
-                if (lane == kq && !q_is_bound && gq == G_H) {
-                    double tt = fmax(c.wH - lam_q, 0.0);
-                    if (tt < t1) { t1 = tt; ev = (EV_CAPIN << 16) | (lane << 5); }
-                }
-                if (lane == kq && q_is_bound && gq == G_H) {
-                    // incoming slack bound of a penalised row: the row's own multiplier
-                    // w + q*xi - mu must stay >= 0 while xi rises with the step
-                    const double xi_now = L.lbH - viol, den = 1.0 - c.qH * zz;
-                    if (den > 0.0) {
-                        double tt = fmax(c.wH + c.qH * xi_now - lam_q, 0.0) / den;
-                        if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | R_HWP; }
-                    }
-                }
-                wave_argmin(t1, ev);
-            }
-            const double tstep = fmin(t1, t2);
-            if (!(tstep < 1e299)) {
-                // the incoming normal lies in the span of the working set and nothing can be
-                // dropped.  With a real violation the QP is infeasible; with a rounding-level one
-                // the row is a duplicate of active rows (e.g. a_k pinned by an acceleration AND a
-                // jerk limit): mark it as ignored for this solve.
-                if (best < 1e-7) { if (lane == kq) L.ign |= (1u << qcode); finished = true; break; }
-                st.status = 1; finished = true; break;
-            }
-            lam_q += tstep;
-            if (t2 <= t1) {
-                // full step: the incoming constraint becomes active
-                if (lane == kq) {
-                    if (!q_is_bound) set_code(L, tq, 1);
-                    else if (gq == G_H) set_code(L, R_HWP, 1);      // penalised row turns rigid
-                    else { int p = pivot_of(L, gq); set_code(L, p, 1); }
-                }
-                finished = true;
-            } else {
-                const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
-                if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
-                else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
-                else if (ek == EV_DROPH) { if (lane == el) set_code(L, et, 0); finished = true; }
-                else if (ek == EV_CAPIN) { if (lane == el) set_code(L, R_HWP, 3); finished = true; }
-                else if (ek == EV_CAP) {
-                    int fin = 0;
-                    if (lane == el) {
-                        const int g2 = et;
-                        // members (code 1) of the group with their multipliers after the step
-                        int bestm = -1; double bl = -1e300;
-#pragma unroll
-                        for (int t = R_AMAX; t <= R_VINC; ++t)
-                            if (group_of(t) == g2 && code_of(L, t) == 1) {
-                                double l = L.lamt[t] - tstep * ((m > 0) ? L.rt[t] : 0.0);
-                                if (l > bl) { bl = l; bestm = t; }
-                            }
-                        const int p = pivot_of(L, g2);
-                        const bool q_row_here = (kq == el) && !q_is_bound && gq == g2;
-                        const bool q_bound_here = (kq == el) && q_is_bound && gq == g2;
-                        if (p < 0) {                       // Z -> P
-                            if (bestm < 0) { set_code(L, tq, 2); fin = 1; }
-                            else set_code(L, bestm, 2);
-                        } else {                           // pivot multiplier reached zero
-                            set_code(L, p, 0);
-                            if (bestm >= 0) set_code(L, bestm, 2);
-                            else if (q_row_here) { set_code(L, tq, 2); fin = 1; }
-                            else if (q_bound_here) { fin = 1; }
-                        }
-                    }
-                    if (__any(fin)) finished = true;
-                }
+                if (__any(fin)) finished = true;
             }
         }
-        if (st.status != 0) break;
-        m = rebuild_and_factor(L, c, M, Hs, tauv);
-        if (m < 0) { st.status = 2; break; }
-        if (m > 0) {
-            double g = gradient_side(L, c, M, 0, false, 0.0, 0, 0, 0, 0, 0);
-            if (lane < N) M.yv[lane] = g;
-            WSYNC();
-            double h = hinv_mul(Hs, M.yv, N, lane);
-            double shh, vhh;
-            hom_traj(L, h, shh, vhh);
-            if (lane < N) M.ub[lane] = h;
-            if (lane <= N) { M.sub[lane] = shh; M.vub[lane] = vhh; }
-            WSYNC();
-            solve_multipliers(M, m, lane, N);
-        }
+        if (finished) { have_q = false; lam_q = 0.0; q.al = q.be = q.ga = q.de = q.d = 0.0; }
     }
-    if (st.status == 0 && m > 0) refine_primal(L, c, M, Hs, m, 0.0, 0, 0, 0, 0, 0, grad_total, 4);
-    scatter_to_types<MMAX>(L, M.lam, L.lamt);
+    scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
     st.m = m;
     return st;
 }
@@ -1065,8 +1071,8 @@ struct StepOut { double out[EEPACC_OUT_N]; int status, iters; };
 
 // One ABMPC step for the wave's instance (ABO/RunOpt_ABMPC.m:193-329).  `code` carries the
 // working set between steps (already shifted by the caller).
-template <int MMAX>
-__device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, double* Hs, const StepIn& in,
+template <int MMAX, int NS>
+__device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, double* Hs, const StepIn& in,
                         unsigned long long& code, StepOut& so, double& s_pred, double& v_pred) {
     Lane L;
     L.lane = lane_id(); L.N = C.N;
@@ -1143,10 +1149,10 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX>& M, doubl
     L.a = L.sh = L.vh = L.am1 = 0.0;
     double grad_total = 0.0;
     // per-wave inverse of the effective Hessian: start from the step-invariant H^-1
-    he_load_base(Hs, C.Hinv, N, lane);
+    he_load_base<NS>(Hs, C.Hinv, N, lane);
     L.kmask = 0ull;
     WSYNC();
-    SolveStats st = solve_qp<MMAX>(L, c, M, Hs, C.Hinv, C.tau, C.max_iter, grad_total);
+    SolveStats st = solve_qp<MMAX, NS>(L, c, M, Hs, C.Hinv, C.tau, C.max_iter, grad_total);
     code = L.code;
     // recover z = Psi x + d (A7): predicted states
     s_pred = sf + L.sh; v_pred = vf + L.vh;
@@ -1204,23 +1210,22 @@ __device__ __forceinline__ unsigned long long shift_codes(unsigned long long cod
     return code;
 }
 
-constexpr int kWavesPerBlock = 4;
 
 // LDS layout of a block: per wave [WaveMem][He: N x N doubles]
-__host__ __device__ inline size_t wave_bytes(size_t wm, int N) {
-    return ((wm + (size_t)N * N * sizeof(double)) + 15) & ~(size_t)15;
+__host__ __device__ inline size_t wave_bytes(size_t wm, int ns) {
+    return ((wm + (size_t)ns * ns * sizeof(double)) + 15) & ~(size_t)15;
 }
 
-template <int MMAX>
-__device__ WaveMem<MMAX>* wave_mem(unsigned char* smem, int N, double*& He) {
-    unsigned char* base = smem + wave_bytes(sizeof(WaveMem<MMAX>), N) * (threadIdx.x >> 6);
-    He = reinterpret_cast<double*>(base + sizeof(WaveMem<MMAX>));
-    return reinterpret_cast<WaveMem<MMAX>*>(base);
+template <int MMAX, int NS>
+__device__ WaveMem<MMAX, NS>* wave_mem(unsigned char* smem, int N, double*& He) {
+    unsigned char* base = smem + wave_bytes(sizeof(WaveMem<MMAX, NS>), NS) * (threadIdx.x >> 6);
+    He = reinterpret_cast<double*>(base + sizeof(WaveMem<MMAX, NS>));
+    return reinterpret_cast<WaveMem<MMAX, NS>*>(base);
 }
 
 // B2: one step for B instances.  state: per instance 64 x uint64 codes (instance-major).
-template <int MMAX>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 2)
+template <int MMAX, int NS, int WPB>
+__global__ void __launch_bounds__(64 * WPB, ((NS <= 32 && WPB >= 4) ? 2 : 1))
 k_ab_step(const DevCfg* __restrict__ Cp, int B,
           const double* __restrict__ s, const double* __restrict__ v, const double* __restrict__ a_prev,
           const double* __restrict__ t0, const double* __restrict__ s_tv, const double* __restrict__ v_tv,
@@ -1229,16 +1234,16 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
           int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
-    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int b = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (b >= B) return;
     double* Hs;
-    WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
+    WaveMem<MMAX, NS>& M = *wave_mem<MMAX, NS>(smem, C.N, Hs);
     const int lane = lane_id();
     StepIn in{s[b], v[b], a_prev[b], t0[b], s_tv[b], v_tv[b], a_tv_prev[b]};
     unsigned long long code = codes[(size_t)b * 64 + lane];
     StepOut so;
     double sp, vp;
-    ab_step<MMAX>(C, M, Hs, in, code, so, sp, vp);
+    ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp);
     codes[(size_t)b * 64 + lane] = shift_codes(code, C.N);
     if (lane < EEPACC_OUT_N) {
         double val = 0.0;
@@ -1254,31 +1259,59 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
 // B1: closed loop over n_steps for B instances (ABO/RunOpt_ABMPC.m:154-340).  k_start > 0
 // resumes from the carried per-instance state (carry [6][B]: s, v, Fm, Fb of the previous step,
 // previous lead speed, t_0; codes: shifted working set).
-template <int MMAX>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 2)
+template <int MMAX, int NS, int WPB>
+__global__ void __launch_bounds__(64 * WPB, ((NS <= 32 && WPB >= 4) ? 2 : 1))
 k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
             const double* __restrict__ s0, const double* __restrict__ v0, const double* __restrict__ a_m1,
             const double* __restrict__ s_tv, const double* __restrict__ v_tv,
             double* __restrict__ carry, unsigned long long* __restrict__ codes,
-            double* __restrict__ traj, int32_t* __restrict__ status, int32_t* __restrict__ iters_total) {
+            double* __restrict__ traj, int32_t* __restrict__ status, int32_t* __restrict__ iters_total,
+            int* __restrict__ work_counter, int* __restrict__ done, int kChunkSteps) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
-    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (b >= B) return;
     double* Hs;
-    WaveMem<MMAX>& M = *wave_mem<MMAX>(smem, C.N, Hs);
+    WaveMem<MMAX, NS>& M = *wave_mem<MMAX, NS>(smem, C.N, Hs);
     const int lane = lane_id();
     const double Ts = C.Tvec[0];
+    // Instances take very different numbers of working-set changes (per-instance run times spread
+    // 0.75x..1.7x around the mean), so the simulation is cut into work units (instance, chunk of
+    // kChunkSteps MPC steps) handed out through a device-wide counter in chunk-major order.  The loop
+    // state of an instance travels between units through `carry`/`codes` in HBM: the producer wave
+    // publishes done[b] = chunk+1 behind an agent-scope release, the consumer polls done[b] relaxed
+    // and then takes one agent-scope acquire (cdna_hip_programming.md, Guideline 16).  A unit is only
+    // handed out after its predecessor has been picked by a running wave, so the wait is bounded.
+    const int n_chunks = (n_steps + kChunkSteps - 1) / kChunkSteps;
+    const int n_units = n_chunks * B;
+    for (int fetch = 0; fetch <= n_units; ++fetch) {
+    int u = 0;
+    if (lane == 0) u = atomicAdd(work_counter, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= n_units || u < 0) break;
+    const int chunk = u / B, b = u - chunk * B;
+    const int kk0 = chunk * kChunkSteps;
+    const int kk1 = (kk0 + kChunkSteps < n_steps) ? kk0 + kChunkSteps : n_steps;
+    if (chunk > 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1 << 26)) break;       // never expected; keeps every wave finite
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef EEPACC_DEBUG_TIMING
+    const long long t_begin = wall_clock64();
+#endif
     unsigned long long code = 0ull;
     double s_prev = 0, v_prev = 0, Fm_prev = 0, Fb_prev = 0, v_tv_measured = 0.0, t_0 = 0.0;
-    if (k_start > 0) {
+    if (k_start + kk0 > 0) {
         s_prev = carry[0 * (size_t)B + b]; v_prev = carry[1 * (size_t)B + b];
         Fm_prev = carry[2 * (size_t)B + b]; Fb_prev = carry[3 * (size_t)B + b];
         v_tv_measured = carry[4 * (size_t)B + b]; t_0 = carry[5 * (size_t)B + b];
         code = codes[(size_t)b * 64 + lane];
     }
     int it_total = 0;
-    for (int kk = 0; kk < n_steps; ++kk) {
+    for (int kk = kk0; kk < kk1; ++kk) {
         StepIn in;
         if (k_start + kk == 0) {                             // :159-172
             in.s = s0[b]; in.v = v0[b]; in.a_prev = a_m1[b];
@@ -1298,7 +1331,7 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
         in.t0 = t_0;
         StepOut so;
         double sp, vp;
-        ab_step<MMAX>(C, M, Hs, in, code, so, sp, vp);
+        ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp);
         code = shift_codes(code, C.N);
         if (lane < EEPACC_OUT_N) {
             double val = 0.0;
@@ -1317,7 +1350,19 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
         carry[0 * (size_t)B + b] = s_prev; carry[1 * (size_t)B + b] = v_prev;
         carry[2 * (size_t)B + b] = Fm_prev; carry[3 * (size_t)B + b] = Fb_prev;
         carry[4 * (size_t)B + b] = v_tv_measured; carry[5 * (size_t)B + b] = t_0;
-        if (iters_total) iters_total[b] = it_total;
+#ifdef EEPACC_DEBUG_TIMING
+        if (iters_total) atomicAdd(&iters_total[b], (int)((wall_clock64() - t_begin) / 100));   // microseconds
+#else
+        if (iters_total) atomicAdd(&iters_total[b], it_total);
+#endif
+    }
+    // publish the unit: all of this wave's stores, then release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&done[b], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
 }
 
@@ -1357,43 +1402,72 @@ __global__ void k_postprocess(const DevCfg* __restrict__ Cp, int B, int n_steps,
 namespace eepacc {
 
 // working-set capacity: rigid rows are linearly independent, so m <= N (+ terminal rows)
-constexpr int kMMaxSmall = 36;     // N <= 34
-constexpr int kMMaxLarge = 66;     // N <= 63
+constexpr int kMMaxSmall = 34, kNSSmall = 32;     // N <= 32: 8 waves / CU
+constexpr int kMMaxLarge = 66, kNSLarge = 64;     // N <= 63: 2 waves / CU
+
+static int waves_per_block() {
+    static int w = -1;
+    if (w < 0) {
+        const char* e = getenv("EEPACC_WPB");
+        w = (e && atoi(e) == 1) ? 1 : 4;
+    }
+    return w;
+}
 
 size_t ab_smem_bytes(int N) {
-    size_t wm = N <= kMMaxSmall - 2 ? sizeof(WaveMem<kMMaxSmall>) : sizeof(WaveMem<kMMaxLarge>);
-    return wave_bytes(wm, N) * kWavesPerBlock;
+    return N <= kNSSmall ? wave_bytes(sizeof(WaveMem<kMMaxSmall, kNSSmall>), kNSSmall) * waves_per_block()
+                         : wave_bytes(sizeof(WaveMem<kMMaxLarge, kNSLarge>), kNSLarge) * 2;
 }
+
+#define EEPACC_LAUNCH(KERNEL, MM, NSV, WPB, ...)                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<MM, NSV, WPB>), dim3((B + WPB - 1) / WPB), dim3(64 * WPB),  \
+                       ab_smem_bytes(N), stream, __VA_ARGS__)
 
 hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream) {
-    const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (N <= kMMaxSmall - 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMaxSmall>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                           ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
-                           s_pred, v_pred, status, iters);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ab_step<kMMaxLarge>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                           ab_smem_bytes(N), stream, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out,
-                           s_pred, v_pred, status, iters);
+    if (N > kNSSmall) EEPACC_LAUNCH(k_ab_step, kMMaxLarge, kNSLarge, 2, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
+    else if (waves_per_block() == 1) EEPACC_LAUNCH(k_ab_step, kMMaxSmall, kNSSmall, 1, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
+    else EEPACC_LAUNCH(k_ab_step, kMMaxSmall, kNSSmall, 4, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
     return hipGetLastError();
 }
+
+#define EEPACC_LAUNCH_GRID(KERNEL, MM, NSV, WPB, GRID, ...)                                               \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<MM, NSV, WPB>), dim3(GRID), dim3(64 * WPB), ab_smem_bytes(N), stream, __VA_ARGS__)
 
 hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
-                            int32_t* status, int32_t* iters_total, hipStream_t stream) {
-    const int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (N <= kMMaxSmall - 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMaxSmall>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                           ab_smem_bytes(N), stream, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes,
-                           traj, status, iters_total);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_run_abmpc<kMMaxLarge>), dim3(blocks), dim3(64 * kWavesPerBlock),
-                           ab_smem_bytes(N), stream, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes,
-                           traj, status, iters_total);
+                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int num_cus,
+                            hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(done, 0, sizeof(int) * (size_t)B, stream);
+    if (e != hipSuccess) return e;
+    if (iters_total) {
+        e = hipMemsetAsync(iters_total, 0, sizeof(int32_t) * (size_t)B, stream);
+        if (e != hipSuccess) return e;
+    }
+    static int kChunkSteps = -1;
+    if (kChunkSteps < 0) {
+        const char* ev = getenv("EEPACC_CHUNK");
+        kChunkSteps = (ev && atoi(ev) > 0) ? atoi(ev) : kChunkStepsDefault;
+    }
+    const int n_units = ((n_steps + kChunkSteps - 1) / kChunkSteps) * B;
+    // one chip-filling wave of blocks: LDS admits 8 (small) / 2 (large) waves per CU
+    if (N > kNSSmall) {
+        int grid = num_cus * 1, need = (n_units + 1) / 2;
+        if (grid > need) grid = need;
+        EEPACC_LAUNCH_GRID(k_run_abmpc, kMMaxLarge, kNSLarge, 2, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps);
+    } else if (waves_per_block() == 1) {
+        int grid = num_cus * 8; if (grid > n_units) grid = n_units;
+        EEPACC_LAUNCH_GRID(k_run_abmpc, kMMaxSmall, kNSSmall, 1, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps);
+    } else {
+        int grid = num_cus * 2, need = (n_units + 3) / 4;
+        if (grid > need) grid = need;
+        EEPACC_LAUNCH_GRID(k_run_abmpc, kMMaxSmall, kNSSmall, 4, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps);
+    }
     return hipGetLastError();
 }
 
@@ -1404,9 +1478,13 @@ hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double
 }
 
 hipError_t set_max_smem() {
-    const void* fns[4] = {reinterpret_cast<const void*>(&k_ab_step<kMMaxSmall>), reinterpret_cast<const void*>(&k_ab_step<kMMaxLarge>),
-                          reinterpret_cast<const void*>(&k_run_abmpc<kMMaxSmall>), reinterpret_cast<const void*>(&k_run_abmpc<kMMaxLarge>)};
-    for (int i = 0; i < 4; ++i) {
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_ab_step<kMMaxSmall, kNSSmall, 1>),
+                          reinterpret_cast<const void*>(&k_ab_step<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&k_ab_step<kMMaxLarge, kNSLarge, 2>),
+                          reinterpret_cast<const void*>(&k_run_abmpc<kMMaxSmall, kNSSmall, 1>),
+                          reinterpret_cast<const void*>(&k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&k_run_abmpc<kMMaxLarge, kNSLarge, 2>)};
+    for (int i = 0; i < 6; ++i) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
