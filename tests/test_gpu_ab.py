@@ -72,7 +72,7 @@ def test_closed_loop_golden_trajectory(tree, torch_mod):
     assert np.array_equal(both, tr)
 
 
-@pytest.mark.parametrize("tree,N,B", [("ABO", 20, 192), ("ABO", 30, 96), ("ORIG", 30, 48)])
+@pytest.mark.parametrize("tree,N,B", [("ABO", 20, 192), ("ABO", 30, 96), ("ORIG", 30, 48), ("ABO", 60, 12)])
 def test_open_loop_seeded_batch_vs_oracle(tree, N, B, torch_mod):
     """S1 inputs (perturbed golden states): every output incl. predicted trajectories and cost."""
     from oracle import Oracle
