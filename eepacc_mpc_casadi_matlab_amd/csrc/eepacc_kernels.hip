@@ -148,7 +148,6 @@ struct Lane {
     double chw;                   // headway-policy coefficient T_hwp + G_hwp*v_est(k)
     double g0;                    // base gradient of the condensed objective
     double a, sh, vh, am1;        // acceleration and homogeneous trajectories, a_{k-1}
-    double lamt[kNumRowTypes], rt[kNumRowTypes];
     int base;                     // first working-set position of this lane's rows
 };
 
@@ -484,19 +483,6 @@ __device__ __forceinline__ void solve_multipliers(WaveMem<MMAX, NS>& M, int m, i
     WSYNC();
 }
 
-// scatter working-set vector x[pos] back to the owning (lane, type) registers
-template <int MMAX, int NS>
-__device__ __forceinline__ void scatter_to_types(const Lane& L, const double* x, double* out) {
-    int pos = L.base;
-#pragma unroll
-    for (int t = 0; t < kNumRowTypes; ++t) {
-        int cd = code_of(L, t);
-        double v = 0.0;
-        if (cd == 1) { v = x[pos]; ++pos; }
-        out[t] = v;
-    }
-}
-
 // primal point from the multipliers: a = -Hinv (g_eff + lam_q c_q + C' lam); also refreshes the
 // homogeneous trajectories and their LDS images (av/shv/vhv)
 template <int MMAX, int NS>
@@ -571,13 +557,16 @@ __device__ __forceinline__ int warm_repair(Lane& L, const Cfg& c, const WaveMem<
     const double tol = kTolDual * (1.0 + lmax);
     int changed = 0;
     double sumF = 0.0, sumS = 0.0, sumV = 0.0;
+    double bestF = -1e300, bestS = -1e300, bestV = -1e300;     // largest multiplier per group
+    int bF = -1, bS = -1, bV = -1;
     double worst = tol; int fix = 0x7fffffff;
+    int pos = L.base;
 #pragma unroll
     for (int t = 0; t < kNumRowTypes; ++t) {
         int cd = code_of(L, t);
         if (cd != 1) continue;
         int g2 = lane_group(L, t);
-        double l = L.lamt[t];
+        double l = M.lam[pos++];
         if (g2 == G_H) {
             if (-l > tol) {
                 if (!single) { set_code(L, t, 0); changed = 1; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
@@ -587,7 +576,9 @@ __device__ __forceinline__ int warm_repair(Lane& L, const Cfg& c, const WaveMem<
         } else {
             if (-l > tol) {
                 if (!single) { set_code(L, t, 0); changed = 1; l = 0.0; } else if (-l > worst) { worst = -l; fix = (EV_DROP << 16) | (lane << 5) | t; }
-            }
+            } else if (g2 == G_F) { if (l > bestF) { bestF = l; bF = t; } }
+            else if (g2 == G_S) { if (l > bestS) { bestS = l; bS = t; } }
+            else if (g2 == G_V) { if (l > bestV) { bestV = l; bV = t; } }
             if (g2 == G_F) sumF += l; else if (g2 == G_S) sumS += l; else if (g2 == G_V) sumV += l;
         }
     }
@@ -613,8 +604,8 @@ __device__ __forceinline__ int warm_repair(Lane& L, const Cfg& c, const WaveMem<
             const int ek = fix >> 16;
             el = (fix >> 5) & 63; et = fix & 31;
             if (lane == el) {
-                if (ek == EV_DROP) { set_code(L, et, 0); el = -1; }
-                else if (ek == EV_COMPL) { set_code(L, et, 3); el = -1; }
+                if (ek == EV_DROP) set_code(L, et, 0);
+                else if (ek == EV_COMPL) set_code(L, et, 3);
             }
             if (ek != EV_CAP) el = -1;
         } else el = -1;
@@ -622,11 +613,8 @@ __device__ __forceinline__ int warm_repair(Lane& L, const Cfg& c, const WaveMem<
     if (lane == el) {          // group cap violated: make the member with the largest multiplier the pivot
         int p = pivot_of(L, et);
         if (p >= 0) set_code(L, p, 0);
-        int bestt = -1; double bl = -1e300;
-#pragma unroll
-        for (int t = R_AMAX; t <= R_VINC; ++t)
-            if (group_of(t) == et && code_of(L, t) == 1 && L.lamt[t] > bl) { bl = L.lamt[t]; bestt = t; }
-        if (bestt >= 0) set_code(L, bestt, 2);
+        int bestt = et == G_F ? bF : (et == G_S ? bS : bV);
+        if (bestt >= 0 && code_of(L, bestt) == 1) set_code(L, bestt, 2);
     }
     return __any(changed);
 }
@@ -750,7 +738,6 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         refine_primal(L, c, M, Hs, m, lam_q, q.kq, q.al, q.be, q.ga, q.de, grad_total, 4);
         if (warm) {
             if (m > 0) {
-                scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
                 if (warm_repair(L, c, M, m, pass < kSinglePasses)) {
                     if (++pass >= kSinglePasses + 6) {
                         L.code = 0ull;
@@ -815,18 +802,19 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         const double zz = cu - sr;
         double t2 = (zz > 1e-8 * cu) ? viol / zz : kInf;
         if (viol <= 0.0) t2 = 0.0;
-        // blocking events, evaluated per (lane, type)
-        scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
-        scatter_to_types<MMAX, NS>(L, M.rv, L.rt);
+        // blocking events, evaluated per (lane, type); multipliers and their rates are read from the
+        // working-set list in this lane's order
         double t1 = kInf; int ev = 0x7fffffff;
         {
             double sumLF = 0, sumLS = 0, sumLV = 0, sumRF = 0, sumRS = 0, sumRV = 0;
+            int pos = L.base;
 #pragma unroll
             for (int t = 0; t < kNumRowTypes; ++t) {
                 int cd = code_of(L, t);
                 if (cd != 1) continue;
                 int g2 = lane_group(L, t);
-                double l = L.lamt[t], r = (m > 0) ? L.rt[t] : 0.0;
+                const double l = M.lam[pos], r = M.rv[pos];
+                ++pos;
                 if (g2 == G_H) {
                     // rigid row of the quadratic slack: 0 <= lambda <= w
                     if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
@@ -895,12 +883,14 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
                     const int g2 = et;
                     // members (code 1) of the group with their multipliers after the step
                     int bestm = -1; double bl = -1e300;
+                    int pos = L.base;
 #pragma unroll
-                    for (int t = R_AMAX; t <= R_VINC; ++t)
-                        if (group_of(t) == g2 && code_of(L, t) == 1) {
-                            double l = L.lamt[t] - tstep * ((m > 0) ? L.rt[t] : 0.0);
-                            if (l > bl) { bl = l; bestm = t; }
-                        }
+                    for (int t = 0; t < kNumRowTypes; ++t) {
+                        if (code_of(L, t) != 1) continue;
+                        const double l = M.lam[pos] - tstep * M.rv[pos];
+                        ++pos;
+                        if (t >= R_AMAX && t <= R_VINC && group_of(t) == g2 && l > bl) { bl = l; bestm = t; }
+                    }
                     const int p = pivot_of(L, g2);
                     const bool q_row_here = (kq == el) && !q.is_bound && q.gq == g2;
                     const bool q_bound_here = (kq == el) && q.is_bound && q.gq == g2;
@@ -919,7 +909,6 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         }
         if (finished) { have_q = false; lam_q = 0.0; q.al = q.be = q.ga = q.de = q.d = 0.0; }
     }
-    scatter_to_types<MMAX, NS>(L, M.lam, L.lamt);
     st.m = m;
     return st;
 }
