@@ -177,3 +177,61 @@ def test_edge_cases(torch_mod, lead_trace):
     e = torch.empty(0, dtype=torch.float64, device="cuda")
     eng.run_abmpc(e, e, e, torch.empty((3, 0), dtype=torch.float64, device="cuda"),
                   torch.empty((3, 0), dtype=torch.float64, device="cuda"))
+
+
+def _route_case(tree, N, **kw):
+    """A route with every feature of EstimateRouteAndComfortBounds switched on."""
+    from eepacc_mpc_casadi_matlab_amd.settings import Settings, SetVehicleParameters, default_opt
+    OPT = default_opt()
+    OPT.update(slopes=np.array([[3.0, 40, 160], [-2.0, 300, 420]]),
+               speedLimZones=np.array([[50.0, 0.0], [30.0, 150.0], [70.0, 400.0]]),
+               curves=np.array([[-1 / 25.0, 90, 120], [1 / 60.0, 250, 300]]),
+               stopLoc=np.array([200.0, 520.0]),
+               TLLoc=np.array([[330.0, 5.0, 20.0, 25.0], [600.0, 0.0, 15.0, 15.0]]))
+    OPT = Settings(OPT, tree=tree, N_hor=N)
+    OPT.update(kw)
+    return OPT, SetVehicleParameters(tree)
+
+
+@pytest.mark.parametrize("tree", ["ABO", "ORIG"])
+def test_route_features_and_estimator_modes(tree, torch_mod, lead_trace):
+    """Speed-limit steps, curves, stops, traffic lights, road slope (non-constant: the sin/cos path of
+    the plant), and the constant-velocity estimator modes -- none of these has a reference golden, the
+    oracle is the checker (closed loop, 90 steps)."""
+    from oracle import Oracle
+    for est in (dict(), dict(paramEstSetting=0, TVestSetting=0)):
+        OPT, V = _route_case(tree, 20, **est)
+        B, n_steps = 4, 90
+        sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=7)
+        sc["s_tv"] = sc["s_tv"] + np.array([5.0, 60.0, 150.0, 1e4])[None, :]     # from tight following to a free road
+        eng = _engine(OPT, V, 8)
+        traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+        tr = traj.cpu().numpy(); st = status.cpu().numpy()
+        orc = Oracle(OPT, V)
+        tol = dict(s=1e-7, v=1e-8, a=1e-8, xi_v=1e-8, xi_h=1e-8, xi_s=1e-8, xi_f=1e-8, Fm=1e-4, Fb=1e-4)
+        for i in range(B):
+            ref, rst, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+            assert np.array_equal(rst != 0, st[:, i] != 0), (tree, est, i)
+            ok = rst == 0
+            for n, t in tol.items():
+                assert np.abs(tr[ok, OUT[n], i] - ref[ok, OUT[n]]).max() < t, (tree, est, i, n)
+
+
+def test_variable_time_steps(torch_mod, lead_trace):
+    """Geometric Tvec (the commented option of ABO/Settings.m:120-121): general-T condensing scans."""
+    from oracle import Oracle
+    OPT, V, _, _ = make_case("ABO", 24)
+    Ts, TsMax, N = 0.5, 1.5, 24
+    OPT["Tvec"] = Ts * (TsMax / Ts) ** (np.arange(N) / (N - 1))
+    B, n_steps = 3, 60
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=3)
+    eng = _engine(OPT, V, 4)
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        ref, rst, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        assert rst.sum() == 0
+        for n in ("s", "v", "Fm", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
+            assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (i, n)
