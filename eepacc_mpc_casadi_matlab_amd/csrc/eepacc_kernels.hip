@@ -508,7 +508,7 @@ __device__ __forceinline__ void primal_from_multipliers(Lane& L, const Cfg& c, W
 template <int MMAX, int NS>
 __device__ __forceinline__ void refine_primal(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, const double* Hs, int m,
                                               double lam_q, int kq, double qal, double qbe, double qga, double qde,
-                                              double& grad_total, int max_rounds) {
+                                              double& grad_total, int max_rounds, double res_tol) {
     primal_from_multipliers(L, c, M, Hs, m, lam_q, kq, qal, qbe, qga, qde, grad_total);
     if (m == 0) return;
     for (int round = 0; round < max_rounds; ++round) {
@@ -520,7 +520,7 @@ __device__ __forceinline__ void refine_primal(Lane& L, const Cfg& c, WaveMem<MMA
         }
         int dummy = L.lane;
         wave_argmax(rel, dummy);
-        if (!(rel > 1e-14)) break;
+        if (!(rel > res_tol)) break;
         WSYNC();
         if (L.lane < m) {
             double acc = 0.0;
@@ -735,7 +735,8 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             WSYNC();
             solve_multipliers(M, m, lane, N);
         }
-        refine_primal(L, c, M, Hs, m, lam_q, q.kq, q.al, q.be, q.ga, q.de, grad_total, 4);
+        // working accuracy while the working set is still changing; polished after convergence
+        refine_primal(L, c, M, Hs, m, lam_q, q.kq, q.al, q.be, q.ga, q.de, grad_total, 3, 1e-11);
         if (warm) {
             if (m > 0) {
                 if (warm_repair(L, c, M, m, pass < kSinglePasses)) {
@@ -909,6 +910,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         }
         if (finished) { have_q = false; lam_q = 0.0; q.al = q.be = q.ga = q.de = q.d = 0.0; }
     }
+    if (st.status == 0 && m > 0) refine_primal(L, c, M, Hs, m, 0.0, 0, 0.0, 0.0, 0.0, 0.0, grad_total, 4, 1e-14);
     st.m = m;
     return st;
 }
