@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "eepacc_device.h"
+#include "eepacc_qp_dense.h"
 #include "../../include/eepacc.h"
 
 namespace eepacc {
@@ -46,6 +47,8 @@ struct eepacc_handle {
     int last_B = 0;
     int k_done = 0;                          // closed-loop steps already run since the last reset
     int carry_B = 0;
+    double* d_qp_ws = nullptr;               // workspace of the dense QP operator
+    size_t qp_ws_doubles = 0;
 };
 
 extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
@@ -209,6 +212,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_carry) (void)hipFree(h->d_carry);
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_done) (void)hipFree(h->d_done);
+    if (h->d_qp_ws) (void)hipFree(h->d_qp_ws);
     delete h;
 }
 
@@ -299,6 +303,40 @@ extern "C" int eepacc_last_iterations(eepacc_handle* h, int B, int32_t* iters_ho
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(iters_host, h->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return EEPACC_OK;
+}
+
+// B3 -- dense QP operator (ABO/RunOpt_ABMPC.m:252)
+static int qp_workspace(eepacc_handle* h, int grid, int nV) {
+    size_t need = (size_t)grid * eepacc_qp_dense_ws_doubles(nV);
+    if (need > h->qp_ws_doubles) {
+        if (h->d_qp_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(h->d_qp_ws); h->d_qp_ws = nullptr; h->qp_ws_doubles = 0; }
+        if (hipMalloc(&h->d_qp_ws, need * sizeof(double)) != hipSuccess) return fail(EEPACC_ENOMEM, "dense QP workspace allocation failed");
+        h->qp_ws_doubles = need;
+    }
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, const double* H, const double* g,
+                                       const double* A, const double* lba, const double* uba, const double* lbx,
+                                       const double* ubx, const double* x0, double* x, double* cost,
+                                       int32_t* status, void* stream) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 0 || nV < 1 || nC < 0) return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: bad sizes");
+    if (B == 0) return EEPACC_OK;
+    if (nV > EEPACC_QP_MAX_NV || nC > EEPACC_QP_MAX_NC)
+        return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: nV/nC above EEPACC_QP_MAX_NV/NC");
+    if (!H || !g || !x || (nC > 0 && !A)) return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: NULL buffer");
+    if (eepacc_qp_dense_lds_bytes(nV, nC) > 160 * 1024) return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: problem does not fit LDS");
+    HIPCHK(hipSetDevice(h->device));
+    int grid = B < 2 * h->num_cus ? B : 2 * h->num_cus;
+    int rc = qp_workspace(h, grid, nV);
+    if (rc != EEPACC_OK) return rc;
+    eepacc_qp_args a;
+    a.B = B; a.nV = nV; a.nC = nC; a.H = H; a.g = g; a.A = A; a.lba = lba; a.uba = uba; a.lbx = lbx; a.ubx = ubx;
+    a.x0 = x0; a.x = x; a.cost = cost; a.status = status; a.iters = (B <= h->max_batch) ? h->d_iters : nullptr;
+    a.ws = h->d_qp_ws; a.ws_stride = eepacc_qp_dense_ws_doubles(nV); a.rho_rel = 0.0; a.max_prox = 0;
+    HIPCHK(eepacc_qp_dense_launch(a, grid, (hipStream_t)stream));
     return EEPACC_OK;
 }
 

@@ -1,0 +1,737 @@
+// eepacc_qp_dense.hip -- batched dense QP operator (boundary level B3):
+//     sol = QPsolver('h',H,'g',c,'a',G,'lbx',..,'ubx',..,'lba',g_lb,'uba',g_ub)
+// (ABO/RunOpt_ABMPC.m:252, ABO/RunOpt_FBMPC.m:278; CasADi conic, CAS/+casadi/conic.m:951-966)
+//     min 1/2 x'Hx + g'x   s.t.  lba <= A x <= uba,  lbx <= x <= ubx     (+-inf = absent)
+//
+// One QP per 256-thread workgroup (4 wavefronts); workgroups are persistent and walk the batch.
+// Matrices live in a per-workgroup global workspace (they do not fit LDS for nV >= 150) that
+// stays L2/MALL resident; every vector of the iteration lives in LDS.
+//
+// Method (handles the PSD Hessian of the AB QP and the indefinite one of the FB QP):
+//   proximal outer loop on H + rho I (rho raised until the Cholesky factor exists),
+//   Goldfarb-Idnani dual active set inside, with J = L^-T Q kept TRANSPOSED (JT[j][k]=J[k][j],
+//   so every sweep over a J column is a coalesced row read), R column-major, constraint
+//   addition by one Householder reflector applied by all threads (no serial Givens chain),
+//   removal by Givens on two contiguous JT rows; closed-form crash start on the bounds of
+//   curvature-free variables; exact KKT solve (LU, partial pivoting, iterative refinement) on
+//   the final working set with the unregularised H, and KKT verification.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "eepacc_qp_dense.h"
+
+namespace {
+
+constexpr int QT = 256;
+constexpr int QW = QT / 64;
+
+struct Prob {            // one instance
+    int n, nC, m1;
+    const double *H, *g, *A, *lba, *uba, *lbx, *ubx;
+};
+
+struct Lds {
+    double *x, *xc, *gr, *np, *d, *z, *r, *u, *xp, *up, *t, *hv, *rhs, *sol, *res, *fcol, *ax, *red;
+    int *act, *crash, *piv, *ired;
+    unsigned char* is_act;
+};
+
+struct Ws {              // per-workgroup global workspace
+    double *Hs, *J0T, *JT, *R, *K;      // n^2, n^2, n^2, n^2, (2n+1)^2 ; L aliases K
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ double block_sum(double v, const Lds& S) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) S.red[wave_id()] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < QW; ++w) s += S.red[w];
+    return s;
+}
+
+__device__ double block_max(double v, const Lds& S) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lane_id() == 0) S.red[wave_id()] = v;
+    __syncthreads();
+    double s = S.red[0];
+#pragma unroll
+    for (int w = 1; w < QW; ++w) s = fmax(s, S.red[w]);
+    return s;
+}
+
+// arg-min with smallest index on ties; idx < 0 means "none"
+__device__ void block_argmin(double& v, int& idx, const Lds& S) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(idx, o);
+        bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+        if (take) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if (lane_id() == 0) { S.red[wave_id()] = v; S.ired[wave_id()] = idx; }
+    __syncthreads();
+    v = S.red[0]; idx = S.ired[0];
+#pragma unroll
+    for (int w = 1; w < QW; ++w) {
+        double ov = S.red[w]; int oi = S.ired[w];
+        bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+        if (take) { v = ov; idx = oi; }
+    }
+}
+
+// one-sided constraint c of the list  sgn * (row or variable) >= b
+__device__ __forceinline__ bool os_get(const Prob& P, int c, int& row, double& sgn, double& b) {
+    if (c < 2 * P.nC) {
+        row = c >> 1;
+        if ((c & 1) == 0) { if (!P.lba) return false; b = P.lba[row]; sgn = 1.0; }
+        else              { if (!P.uba) return false; b = -P.uba[row]; sgn = -1.0; }
+    } else {
+        int cc = c - 2 * P.nC;
+        row = -(cc >> 1) - 1;
+        if ((cc & 1) == 0) { if (!P.lbx) return false; b = P.lbx[cc >> 1]; sgn = 1.0; }
+        else               { if (!P.ubx) return false; b = -P.ubx[cc >> 1]; sgn = -1.0; }
+    }
+    return isfinite(b);
+}
+
+// np <- normal of one-sided constraint c  (all threads)
+__device__ void get_normal(const Prob& P, int c, double* np) {
+    int row; double sgn, b;
+    os_get(P, c, row, sgn, b);
+    for (int j = threadIdx.x; j < P.n; j += QT)
+        np[j] = row >= 0 ? sgn * P.A[(size_t)j * P.nC + row] : (j == -row - 1 ? sgn : 0.0);
+    __syncthreads();
+}
+
+// value of constraint c at x (uniform result)
+__device__ double con_value(const Prob& P, int c, const double* x, const Lds& S) {
+    int row; double sgn, b;
+    os_get(P, c, row, sgn, b);
+    if (row < 0) return sgn * x[-row - 1] - b;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < P.n; j += QT) s += P.A[(size_t)j * P.nC + row] * x[j];
+    s = block_sum(s, S);
+    return sgn * s - b;
+}
+
+// ax = A x
+__device__ void rows_times(const Prob& P, const double* x, double* ax) {
+    for (int i = threadIdx.x; i < P.nC; i += QT) {
+        double s = 0.0;
+        const double* a = P.A + i;
+        for (int j = 0; j < P.n; ++j) s += a[(size_t)j * P.nC] * x[j];
+        ax[i] = s;
+    }
+    __syncthreads();
+}
+
+// dv[j] = sum_k M[j][k] v[k]  (row-major n x n in global, one wavefront per row)
+__device__ void rowdot(const double* M, int n, const double* v, double* out) {
+    for (int j = wave_id(); j < n; j += QW) {
+        const double* row = M + (size_t)j * n;
+        double s = 0.0;
+        for (int k = lane_id(); k < n; k += 64) s += row[k] * v[k];
+        s = wave_sum(s);
+        if (lane_id() == 0) out[j] = s;
+    }
+    __syncthreads();
+}
+
+// out[k] = sum_{j=j0}^{n-1} M[j][k] c[j]  (thread per k)
+__device__ void coldot(const double* M, int n, int j0, const double* c, double* out, double scale) {
+    for (int k = threadIdx.x; k < n; k += QT) {
+        double s = 0.0;
+        for (int j = j0; j < n; ++j) s += M[(size_t)j * n + k] * c[j];
+        out[k] = scale * s;
+    }
+    __syncthreads();
+}
+
+// Cholesky (lower, in place, row-major).  Uniform return: 0 ok, -1 not positive definite.
+__device__ int chol_lower(double* L, int n, const Lds& S) {
+    for (int j = 0; j < n; ++j) {
+        double djj = L[(size_t)j * n + j];
+        if (!(djj > 0.0)) return -1;
+        double l = sqrt(djj);
+        __syncthreads();
+        for (int i = j + threadIdx.x; i < n; i += QT) {
+            double v = (i == j) ? l : L[(size_t)i * n + j] / l;
+            L[(size_t)i * n + j] = v;
+            S.fcol[i] = v;
+        }
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int idx = threadIdx.x; idx < m * m; idx += QT) {
+            int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) L[(size_t)i * n + k] -= S.fcol[i] * S.fcol[k];
+        }
+        __syncthreads();
+    }
+    return 0;
+}
+
+// X = L^-1 (lower triangular, row-major), thread per column
+__device__ void tri_inverse(const double* L, double* X, int n) {
+    for (int c = threadIdx.x; c < n; c += QT) {
+        for (int i = 0; i < n; ++i) {
+            double v = 0.0;
+            if (i >= c) {
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int k = c; k < i; ++k) s -= L[(size_t)i * n + k] * X[(size_t)k * n + c];
+                v = s / L[(size_t)i * n + i];
+            }
+            X[(size_t)i * n + c] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- LU with partial pivoting on K (Nk x Nk row-major, global).  returns min |pivot|
+__device__ double lu_factor(double* K, int Nk, const Lds& S) {
+    double minpiv = INFINITY;
+    for (int k = 0; k < Nk; ++k) {
+        double best = -1.0; int p = -1;
+        for (int i = k + threadIdx.x; i < Nk; i += QT) {
+            double v = fabs(K[(size_t)i * Nk + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        double nb = -best;                 // arg-max as arg-min of the negative, first index on ties
+        block_argmin(nb, p, S);
+        best = -nb;
+        if (threadIdx.x == 0) S.piv[k] = p;
+        if (best < minpiv) minpiv = best;
+        if (best == 0.0) return 0.0;
+        if (p != k)
+            for (int j = threadIdx.x; j < Nk; j += QT) {
+                double t = K[(size_t)k * Nk + j];
+                K[(size_t)k * Nk + j] = K[(size_t)p * Nk + j];
+                K[(size_t)p * Nk + j] = t;
+            }
+        __syncthreads();
+        double inv = 1.0 / K[(size_t)k * Nk + k];
+        for (int i = k + 1 + threadIdx.x; i < Nk; i += QT) {
+            double f = K[(size_t)i * Nk + k] * inv;
+            K[(size_t)i * Nk + k] = f;
+            S.fcol[i] = f;
+        }
+        __syncthreads();
+        const int m = Nk - k - 1;
+        for (int idx = threadIdx.x; idx < m * m; idx += QT) {
+            int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            double f = S.fcol[i];
+            if (f != 0.0) K[(size_t)i * Nk + j] -= f * K[(size_t)k * Nk + j];
+        }
+        __syncthreads();
+    }
+    return minpiv;
+}
+
+__device__ void lu_solve(const double* LU, int Nk, double* b, const Lds& S) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < Nk; ++k) {
+            int p = S.piv[k];
+            if (p != k) { double t = b[k]; b[k] = b[p]; b[p] = t; }
+        }
+    __syncthreads();
+    for (int k = 0; k < Nk; ++k) {
+        double bk = b[k];
+        __syncthreads();
+        for (int i = k + 1 + threadIdx.x; i < Nk; i += QT) b[i] -= LU[(size_t)i * Nk + k] * bk;
+        __syncthreads();
+    }
+    for (int i = Nk - 1; i >= 0; --i) {
+        double bi = b[i] / LU[(size_t)i * Nk + i];
+        __syncthreads();
+        if (threadIdx.x == 0) b[i] = bi;
+        for (int r = threadIdx.x; r < i; r += QT) b[r] -= LU[(size_t)r * Nk + i] * bi;
+        __syncthreads();
+    }
+}
+
+// Exact KKT solve on the working set act[0..q): [Hm N'; N 0][x; -u] = [-gv; b], Hm = Hs + rho I.
+// Outputs xo[n], uo[q]; kkt[3] (uniform).  returns 0 / -1 (singular).
+__device__ int kkt_solve(const Prob& P, const Ws& W, const Lds& S, double rho, const double* gv,
+                         const int* act, int q, double* xo, double* uo, double kkt[3]) {
+    const int n = P.n, Nk = n + q;
+    double* K = W.K;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Nk * Nk; idx += QT) {
+        int i = idx / Nk, j = idx % Nk;
+        double v = 0.0;
+        if (i < n && j < n) v = W.Hs[(size_t)i * n + j] + (i == j ? rho : 0.0);
+        K[idx] = v;
+    }
+    __syncthreads();
+    for (int c = 0; c < q; ++c) {
+        int row; double sgn, b;
+        os_get(P, act[c], row, sgn, b);
+        for (int j = threadIdx.x; j < n; j += QT) {
+            double v = row >= 0 ? sgn * P.A[(size_t)j * P.nC + row] : (j == -row - 1 ? sgn : 0.0);
+            K[(size_t)(n + c) * Nk + j] = v;
+            K[(size_t)j * Nk + n + c] = v;
+        }
+        if (threadIdx.x == 0) S.rhs[n + c] = b;
+    }
+    for (int i = threadIdx.x; i < n; i += QT) S.rhs[i] = -gv[i];
+    __syncthreads();
+    double minpiv = lu_factor(K, Nk, S);
+    if (minpiv < 1e-13) return -1;
+    for (int i = threadIdx.x; i < Nk; i += QT) S.sol[i] = S.rhs[i];
+    lu_solve(K, Nk, S.sol, S);
+    for (int it = 0; it < 3; ++it) {
+        // residual from the problem data (the factor overwrote K)
+        for (int i = threadIdx.x; i < n; i += QT) {
+            double s = S.rhs[i] - rho * S.sol[i];
+            for (int j = 0; j < n; ++j) s = fma(-W.Hs[(size_t)i * n + j], S.sol[j], s);
+            S.res[i] = s;
+        }
+        __syncthreads();
+        for (int c = 0; c < q; ++c) {
+            int row; double sgn, b;
+            os_get(P, act[c], row, sgn, b);
+            double part = 0.0;
+            double yc = S.sol[n + c];
+            if (row >= 0) {
+                for (int j = threadIdx.x; j < n; j += QT) {
+                    double a = sgn * P.A[(size_t)j * P.nC + row];
+                    part = fma(a, S.sol[j], part);
+                    S.res[j] = fma(-a, yc, S.res[j]);
+                }
+            } else if (threadIdx.x == 0) {
+                int j = -row - 1;
+                part = sgn * S.sol[j];
+                S.res[j] = fma(-sgn, yc, S.res[j]);
+            }
+            part = block_sum(part, S);
+            if (threadIdx.x == 0) S.res[n + c] = S.rhs[n + c] - part;
+        }
+        __syncthreads();
+        lu_solve(K, Nk, S.res, S);
+        for (int i = threadIdx.x; i < Nk; i += QT) S.sol[i] += S.res[i];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += QT) xo[i] = S.sol[i];
+    for (int c = threadIdx.x; c < q; c += QT) uo[c] = -S.sol[n + c];
+    __syncthreads();
+    // verification: stationarity (relative), worst primal violation over all rows, most negative multiplier
+    for (int i = threadIdx.x; i < n; i += QT) {
+        double s = gv[i] + rho * xo[i];
+        for (int j = 0; j < n; ++j) s = fma(W.Hs[(size_t)i * n + j], xo[j], s);
+        S.t[i] = s;
+    }
+    __syncthreads();
+    for (int c = 0; c < q; ++c) {
+        int row; double sgn, b;
+        os_get(P, act[c], row, sgn, b);
+        double uc = uo[c];
+        if (row >= 0) {
+            for (int j = threadIdx.x; j < n; j += QT) S.t[j] = fma(-sgn * P.A[(size_t)j * P.nC + row], uc, S.t[j]);
+        } else if (threadIdx.x == 0) {
+            S.t[-row - 1] -= sgn * uc;
+        }
+        __syncthreads();
+    }
+    double stat = 0.0, scale = 1.0, dneg = 0.0, pviol = 0.0;
+    for (int i = threadIdx.x; i < n; i += QT) { stat = fmax(stat, fabs(S.t[i])); scale = fmax(scale, fabs(gv[i])); }
+    for (int c = threadIdx.x; c < q; c += QT) { dneg = fmax(dneg, -uo[c]); scale = fmax(scale, fabs(uo[c])); }
+    rows_times(P, xo, S.ax);
+    for (int c = threadIdx.x; c < P.m1; c += QT) {
+        int row; double sgn, b;
+        if (!os_get(P, c, row, sgn, b)) continue;
+        double v = (sgn * (row >= 0 ? S.ax[row] : xo[-row - 1]) - b) / (1.0 + fabs(b));
+        pviol = fmax(pviol, -v);
+    }
+    stat = block_max(stat, S); scale = block_max(scale, S); dneg = block_max(dneg, S); pviol = block_max(pviol, S);
+    kkt[0] = stat / scale; kkt[1] = pviol; kkt[2] = dneg / scale;
+    return 0;
+}
+
+// ---- Goldfarb-Idnani working-set updates on (JT, R) -------------------------------------
+// add: S.d = J' np already computed.  Returns 0 ok / -1 dependent.  q is NOT incremented here.
+__device__ int gi_add(const Ws& W, const Lds& S, int n, int q) {
+    double* d = S.d;
+    double part = 0.0;
+    for (int j = q + threadIdx.x; j < n; j += QT) part += d[j] * d[j];
+    double nrm2 = block_sum(part, S);
+    double nrm = sqrt(nrm2);
+    double d0 = d[0], dq = d[q];
+    if (nrm <= 1e-14 * (1.0 + fabs(d0))) {
+        for (int i = threadIdx.x; i <= q; i += QT) W.R[(size_t)q * n + i] = (i < q) ? d[i] : nrm;
+        __syncthreads();
+        return -1;
+    }
+    double alpha = dq >= 0.0 ? -nrm : nrm;
+    double v0 = dq - alpha;
+    // v'v = nrm2 - dq^2 + v0^2
+    double vtv = nrm2 - dq * dq + v0 * v0;
+    double beta = 2.0 / vtv;
+    __syncthreads();
+    if (threadIdx.x == 0) d[q] = v0;           // d[q..n) now holds the reflector v
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += QT) {
+        double t = 0.0;
+        for (int j = q; j < n; ++j) t += W.JT[(size_t)j * n + k] * d[j];
+        t *= beta;
+        for (int j = q; j < n; ++j) W.JT[(size_t)j * n + k] -= t * d[j];
+    }
+    for (int i = threadIdx.x; i <= q; i += QT) W.R[(size_t)q * n + i] = (i < q) ? d[i] : alpha;
+    __syncthreads();
+    return 0;
+}
+
+// drop active constraint at position l (q = count before the drop)
+__device__ void gi_drop(const Ws& W, const Lds& S, int n, int q, int l) {
+    __syncthreads();
+    // shift columns of R and the act/u lists
+    for (int j = l; j < q - 1; ++j) {
+        for (int i = threadIdx.x; i <= j + 1; i += QT) W.R[(size_t)j * n + i] = W.R[(size_t)(j + 1) * n + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = l; j < q - 1; ++j) { S.act[j] = S.act[j + 1]; S.u[j] = S.u[j + 1]; }
+        S.u[q - 1] = S.u[q];
+        S.u[q] = 0.0;
+    }
+    __syncthreads();
+    const int qn = q - 1;
+    for (int j = l; j < qn; ++j) {
+        double a = W.R[(size_t)j * n + j], b = W.R[(size_t)j * n + j + 1];
+        __syncthreads();
+        if (b == 0.0) continue;
+        double h = hypot(a, b), c = a / h, s = b / h;
+        for (int k = j + threadIdx.x; k < qn; k += QT) {
+            double x = W.R[(size_t)k * n + j], y = W.R[(size_t)k * n + j + 1];
+            W.R[(size_t)k * n + j] = c * x + s * y;
+            W.R[(size_t)k * n + j + 1] = -s * x + c * y;
+        }
+        for (int k = threadIdx.x; k < n; k += QT) {
+            double x = W.JT[(size_t)j * n + k], y = W.JT[(size_t)(j + 1) * n + k];
+            W.JT[(size_t)j * n + k] = c * x + s * y;
+            W.JT[(size_t)(j + 1) * n + k] = -s * x + c * y;
+        }
+        __syncthreads();
+    }
+}
+
+// GI solve of  min 1/2 x'(Hs+rho I)x + gr'x  s.t. list.  Returns 0 ok, 1 infeasible, 2 limit.
+__device__ int gi_solve(const Prob& P, const Ws& W, const Lds& S, double rho, int n_crash_in,
+                        int& q_out, int& iters_out, int max_iter) {
+    const int n = P.n;
+    int n_crash = n_crash_in;
+restart:
+    int q = 0, iters = 0, status = 0;
+    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += QT) W.JT[idx] = W.J0T[idx];
+    for (int c = threadIdx.x; c < P.m1; c += QT) S.is_act[c] = 0;
+    __syncthreads();
+    // x = -G^-1 gr = -J (J' gr)
+    rowdot(W.JT, n, S.gr, S.t);
+    coldot(W.JT, n, 0, S.t, S.x, -1.0);
+    if (n_crash > 0) {
+        // closed-form crash start: the crash variables have no curvature, so with H + rho I they
+        // decouple: x_var = b/coef, multiplier (gr_var + rho x_var)/coef; negative ones are left out
+        int dependent = 0;
+        for (int i = 0; i < n_crash; ++i) {
+            int c = S.crash[i];
+            int row; double sgn, b;
+            os_get(P, c, row, sgn, b);
+            int var = S.crash[n + i];
+            double coef = row >= 0 ? P.A[(size_t)var * P.nC + row] : 1.0;
+            double xv = b / coef;
+            double uu = (S.gr[var] + rho * xv) / coef;
+            if (uu < 0.0) continue;
+            get_normal(P, c, S.np);
+            rowdot(W.JT, n, S.np, S.d);
+            if (gi_add(W, S, n, q) != 0) { dependent = 1; break; }
+            if (threadIdx.x == 0) { S.act[q] = c; S.u[q] = uu; S.is_act[c] = 1; S.x[var] = xv; }
+            ++q;
+            __syncthreads();
+        }
+        if (dependent) { n_crash = 0; goto restart; }
+    }
+    __syncthreads();
+    int refreshes = 0;
+    for (;;) {
+        rows_times(P, S.x, S.ax);
+        double worst = 0.0; int p = -1;
+        for (int c = threadIdx.x; c < P.m1; c += QT) {
+            int row; double sgn, b;
+            if (S.is_act[c] || !os_get(P, c, row, sgn, b)) continue;
+            double s = sgn * (row >= 0 ? S.ax[row] : S.x[-row - 1]) - b;
+            double tol = 1e-11 * (1.0 + fabs(b));
+            if (s < -tol && s < worst) { worst = s; p = c; }
+        }
+        block_argmin(worst, p, S);
+        if (p < 0) {
+            if (refreshes < 1 && q > 0) {
+                double kk[3];
+                int okr = kkt_solve(P, W, S, rho, S.gr, S.act, q, S.xp, S.up, kk) == 0;
+                if (okr) {
+                    double mn = 0.0;
+                    for (int j = threadIdx.x; j < q; j += QT) mn = fmax(mn, -S.up[j]);
+                    mn = block_max(mn, S);
+                    if (mn > 0.0) okr = 0;
+                }
+                if (okr) {
+                    for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
+                    for (int j = threadIdx.x; j < q; j += QT) S.u[j] = S.up[j];
+                    __syncthreads();
+                }
+                ++refreshes;
+                if (okr) continue;
+            }
+            break;
+        }
+        if (++iters > max_iter) { status = 2; break; }
+        get_normal(P, p, S.np);
+        if (threadIdx.x == 0) S.u[q] = 0.0;
+        __syncthreads();
+        int dropped_guard = 0;
+        for (;;) {
+            rowdot(W.JT, n, S.np, S.d);
+            coldot(W.JT, n, q, S.d, S.z, 1.0);
+            double pz = 0.0, p1 = 0.0;
+            for (int j = threadIdx.x; j < n; j += QT) { double v = S.d[j] * S.d[j]; if (j >= q) pz += v; else p1 += v; }
+            double znorm2 = block_sum(pz, S), d1n = block_sum(p1, S);
+            // r = R^-1 d1 (column-oriented back substitution)
+            for (int i = threadIdx.x; i < q; i += QT) S.r[i] = S.d[i];
+            __syncthreads();
+            for (int k = q - 1; k >= 0; --k) {
+                double rk = S.r[k] / W.R[(size_t)k * n + k];
+                __syncthreads();
+                if (threadIdx.x == 0) S.r[k] = rk;
+                for (int i = threadIdx.x; i < k; i += QT) S.r[i] -= W.R[(size_t)k * n + i] * rk;
+                __syncthreads();
+            }
+            int z_zero = (znorm2 <= 1e-26 * (1.0 + d1n + znorm2));
+            double t1 = INFINITY; int l = -1;
+            for (int j = threadIdx.x; j < q; j += QT)
+                if (S.r[j] > 0.0) {
+                    double t = S.u[j] / S.r[j];
+                    if (t < t1) { t1 = t; l = j; }
+                }
+            block_argmin(t1, l, S);
+            if (l < 0) t1 = INFINITY;
+            double sp = con_value(P, p, S.x, S);
+            double t2 = z_zero ? INFINITY : -sp / znorm2;
+            if (t2 < 0.0) t2 = 0.0;
+            double t = t1 < t2 ? t1 : t2;
+            if (!isfinite(t)) { status = 1; goto done; }
+            if (z_zero || t2 == INFINITY) {
+                __syncthreads();
+                for (int j = threadIdx.x; j < q; j += QT) S.u[j] -= t * S.r[j];
+                if (threadIdx.x == 0) { S.u[q] += t; S.is_act[S.act[l]] = 0; }
+                gi_drop(W, S, n, q, l);
+                --q;
+                if (++dropped_guard > 4 * n + 16) { status = 2; goto done; }
+                continue;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += QT) S.x[i] += t * S.z[i];
+            for (int j = threadIdx.x; j < q; j += QT) S.u[j] -= t * S.r[j];
+            if (threadIdx.x == 0) S.u[q] += t;
+            __syncthreads();
+            if (t == t2) {
+                if (gi_add(W, S, n, q) == 0) {
+                    if (threadIdx.x == 0) { S.act[q] = p; S.is_act[p] = 1; }
+                    ++q;
+                }
+                __syncthreads();
+                break;
+            }
+            if (threadIdx.x == 0) S.is_act[S.act[l]] = 0;
+            gi_drop(W, S, n, q, l);
+            --q;
+            if (++dropped_guard > 4 * n + 16) { status = 2; goto done; }
+        }
+    }
+done:
+    __syncthreads();
+    q_out = q;
+    iters_out = iters;
+    return status;
+}
+
+__device__ void carve(Lds& S, unsigned char* base, int n, int nC) {
+    double* p = (double*)base;
+    const int n2 = 2 * n + 2;
+    S.x = p; p += n; S.xc = p; p += n; S.gr = p; p += n; S.np = p; p += n; S.d = p; p += n;
+    S.z = p; p += n; S.r = p; p += n; S.u = p; p += n + 2; S.xp = p; p += n; S.up = p; p += n + 2;
+    S.t = p; p += n; S.hv = p; p += n;
+    S.rhs = p; p += n2; S.sol = p; p += n2; S.res = p; p += n2; S.fcol = p; p += n2;
+    S.ax = p; p += nC; S.red = p; p += 8;
+    int* ip = (int*)p;
+    S.act = ip; ip += n + 2; S.crash = ip; ip += 2 * n; S.piv = ip; ip += n2; S.ired = ip; ip += 8;
+    S.is_act = (unsigned char*)ip;
+}
+
+__global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = a.nV, nC = a.nC;
+    Lds S;
+    carve(S, smem, n, nC);
+    Ws W;
+    {
+        double* w = a.ws + (size_t)blockIdx.x * a.ws_stride;
+        const size_t nn = (size_t)n * n;
+        W.Hs = w; W.J0T = w + nn; W.JT = w + 2 * nn; W.R = w + 3 * nn; W.K = w + 4 * nn;
+    }
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        Prob P;
+        P.n = n; P.nC = nC; P.m1 = 2 * (nC + n);
+        P.H = a.H + (size_t)b * n * n;
+        P.g = a.g + (size_t)b * n;
+        P.A = a.A + (size_t)b * nC * n;
+        P.lba = a.lba ? a.lba + (size_t)b * nC : nullptr;
+        P.uba = a.uba ? a.uba + (size_t)b * nC : nullptr;
+        P.lbx = a.lbx ? a.lbx + (size_t)b * n : nullptr;
+        P.ubx = a.ubx ? a.ubx + (size_t)b * n : nullptr;
+        // symmetrised Hessian, diagonal scale
+        double hm = 0.0;
+        for (int idx = threadIdx.x; idx < n * n; idx += QT) {
+            int i = idx / n, j = idx % n;
+            W.Hs[idx] = 0.5 * (P.H[idx] + P.H[(size_t)j * n + i]);
+            if (i == j) hm = fmax(hm, fabs(P.H[idx]));
+        }
+        double hmax = block_max(hm, S);
+        if (hmax == 0.0) hmax = 1.0;
+        double rho = (a.rho_rel > 0.0 ? a.rho_rel : 1e-7) * hmax;
+        const int max_prox = a.max_prox > 0 ? a.max_prox : 8;
+        double* L = W.K;
+        int chol_ok = 0;
+        for (int tries = 0; tries < 60; ++tries) {
+            for (int idx = threadIdx.x; idx < n * n; idx += QT) {
+                int i = idx / n, j = idx % n;
+                L[idx] = W.Hs[idx] + (i == j ? rho : 0.0);
+            }
+            __syncthreads();
+            if (chol_lower(L, n, S) == 0) { chol_ok = 1; break; }
+            __syncthreads();
+            rho *= 4.0;
+        }
+        int status = 1, tot_iters = 0, q = 0;
+        if (chol_ok) {
+            tri_inverse(L, W.J0T, n);
+            // crash list: lower bounds of curvature-free variables with positive cost
+            // S.hv[j] = 1 if variable j has any curvature
+            for (int j = threadIdx.x; j < n; j += QT) {
+                double any = 0.0;
+                for (int i = 0; i < n; ++i) any = fmax(any, fmax(fabs(P.H[(size_t)i * n + j]), fabs(P.H[(size_t)j * n + i])));
+                S.hv[j] = any;
+            }
+            // rows with exactly one non-zero: S.ax[i] = column index (or -1)
+            for (int i = threadIdx.x; i < nC; i += QT) {
+                int nnz = 0, var = -1;
+                for (int j = 0; j < n; ++j) if (P.A[(size_t)j * nC + i] != 0.0) { ++nnz; var = j; }
+                S.ax[i] = nnz == 1 ? (double)var : -1.0;
+            }
+            __syncthreads();
+            int n_crash = 0;
+            if (threadIdx.x == 0) {
+                // serial pass keeps the list order of the one-sided list (first bound per variable wins)
+                for (int j = 0; j < n; ++j) S.t[j] = 0.0;     // taken flags
+                for (int c = 0; c < P.m1 && n_crash < n; c += 2) {   // lower sides only
+                    int row; double sgn, bb;
+                    if (!os_get(P, c, row, sgn, bb)) continue;
+                    int var; double coef;
+                    if (row >= 0) {
+                        if (S.ax[row] < 0.0) continue;
+                        var = (int)S.ax[row];
+                        coef = P.A[(size_t)var * nC + row];
+                    } else { var = -row - 1; coef = 1.0; }
+                    if (coef <= 0.0 || S.t[var] != 0.0 || !(P.g[var] > 0.0) || S.hv[var] != 0.0) continue;
+                    S.t[var] = 1.0;
+                    S.crash[n_crash] = c;
+                    S.crash[n + n_crash] = var;
+                    ++n_crash;
+                }
+                S.ired[4] = n_crash;
+            }
+            __syncthreads();
+            n_crash = S.ired[4];
+            for (int i = threadIdx.x; i < n; i += QT) S.xc[i] = a.x0 ? a.x0[(size_t)b * n + i] : 0.0;
+            __syncthreads();
+            for (int it = 0; it < max_prox; ++it) {
+                for (int i = threadIdx.x; i < n; i += QT) S.gr[i] = P.g[i] - rho * S.xc[i];
+                __syncthreads();
+                int iters = 0;
+                int rc = gi_solve(P, W, S, rho, n_crash, q, iters, 20 * (n + P.m1) + 100);
+                tot_iters += iters;
+                if (rc != 0) { status = 1; break; }
+                double kkt[3];
+                int prc = kkt_solve(P, W, S, 0.0, P.g, S.act, q, S.xp, S.up, kkt);
+                if (prc == 0 && kkt[0] < 1e-9 && kkt[1] < 1e-9 && kkt[2] < 1e-9) {
+                    for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
+                    __syncthreads();
+                    status = 0;
+                    break;
+                }
+                double pdx = 0.0, pnx = 0.0;
+                for (int i = threadIdx.x; i < n; i += QT) {
+                    double dd = S.x[i] - S.xc[i];
+                    pdx += dd * dd; pnx += S.x[i] * S.x[i];
+                }
+                double dx = block_sum(pdx, S), nx = block_sum(pnx, S);
+                for (int i = threadIdx.x; i < n; i += QT) S.xc[i] = S.x[i];
+                __syncthreads();
+                if (it > 0 && sqrt(dx) <= 1e-13 * (1.0 + sqrt(nx))) { status = 0; break; }
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += QT) S.x[i] = 0.0;
+        }
+        __syncthreads();
+        // cost = 1/2 x'Hx + g'x
+        double pc = 0.0;
+        for (int i = threadIdx.x; i < n; i += QT) {
+            double hx = 0.0;
+            for (int j = 0; j < n; ++j) hx = fma(P.H[(size_t)i * n + j], S.x[j], hx);
+            pc += (0.5 * hx + P.g[i]) * S.x[i];
+        }
+        double cost = block_sum(pc, S);
+        for (int i = threadIdx.x; i < n; i += QT) a.x[(size_t)b * n + i] = S.x[i];
+        if (threadIdx.x == 0) {
+            if (a.cost) a.cost[b] = cost;
+            if (a.status) a.status[b] = status;
+            if (a.iters) a.iters[b] = tot_iters;
+        }
+    }
+}
+
+}  // namespace
+
+size_t eepacc_qp_dense_ws_doubles(int nV) {
+    const size_t n = (size_t)nV;
+    return 4 * n * n + (2 * n + 2) * (2 * n + 2);
+}
+
+size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
+    const size_t n = (size_t)nV, n2 = 2 * n + 2;
+    size_t dbl = 12 * n + 4 + 4 * n2 + (size_t)nC + 8;
+    size_t ints = (n + 2) + 2 * n + n2 + 8;
+    size_t bytes = dbl * 8 + ints * 4 + 2 * ((size_t)nC + n) + 16;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+hipError_t eepacc_qp_dense_launch(const eepacc_qp_args& a, int grid, hipStream_t stream) {
+    size_t lds = eepacc_qp_dense_lds_bytes(a.nV, a.nC);
+    hipError_t e = hipFuncSetAttribute((const void*)k_qp_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_qp_dense, dim3(grid), dim3(QT), lds, stream, a);
+    return hipGetLastError();
+}

@@ -49,6 +49,7 @@ def load_library() -> C.CDLL:
     lib.eepacc_run_abmpc_host.argtypes = [vp, C.c_int, C.c_int] + [c_double_p] * 5 + [c_double_p, ip]
     lib.eepacc_postprocess.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, vp]
     lib.eepacc_last_iterations.argtypes = [vp, C.c_int, ip]
+    lib.eepacc_qp_solve_batched.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [dp] * 8 + [dp, dp, dp, vp]
     _lib = lib
     return lib
 
@@ -56,7 +57,7 @@ def load_library() -> C.CDLL:
 ABI_SYMBOLS = ["eepacc_last_error", "eepacc_version", "eepacc_sizeof_settings", "eepacc_sizeof_vehicle", "eepacc_create", "eepacc_destroy", "eepacc_reset",
                "eepacc_ab_step", "eepacc_run_abmpc", "eepacc_fb_step", "eepacc_run_fbmpc",
                "eepacc_run_abmpc_host", "eepacc_run_fbmpc_host", "eepacc_postprocess",
-               "eepacc_last_iterations"]
+               "eepacc_last_iterations", "eepacc_qp_solve_batched"]
 
 
 def _check(rc: int):
@@ -147,6 +148,31 @@ class Engine:
         _check(self.lib.eepacc_postprocess(self.h, B, n_steps, traj.data_ptr(), *[o.data_ptr() for o in outs],
                                            self._stream()))
         return outs   # rpm, Tm, P, E
+
+    # B3 ------------------------------------------------------------------------------------
+    def qp_solve_batched(self, H, g, A, lba=None, uba=None, lbx=None, ubx=None, x0=None):
+        """sol = QPsolver('h',H,'g',g,'a',A,'lba',..,'uba',..,'lbx',..,'ubx',..) (ABO/RunOpt_ABMPC.m:252)
+        for a batch.  H [B,nV,nV], g [B,nV], A [B,nC,nV] (row-major rows as in numpy; transposed
+        here to the column-major layout of the C-ABI), bounds [B,nC] / [B,nV] or None.
+        Returns x [B,nV], cost [B], status [B] as device tensors."""
+        t = self.torch
+        f64 = dict(dtype=t.float64, device=self.device)
+        H = t.as_tensor(H, **f64).contiguous()
+        B, nV = H.shape[0], H.shape[1]
+        g = t.as_tensor(g, **f64).contiguous()
+        A = t.as_tensor(A, **f64)
+        nC = A.shape[1]
+        A_cm = A.transpose(1, 2).contiguous()          # [B][nV][nC] = column-major nC x nV
+        opt = lambda v, n: None if v is None else self._d(t.as_tensor(v, **f64).reshape(-1), B * n)
+        lba, uba, lbx, ubx, x0 = opt(lba, nC), opt(uba, nC), opt(lbx, nV), opt(ubx, nV), opt(x0, nV)
+        ptr = lambda v: None if v is None else v.data_ptr()
+        x = t.empty((B, nV), **f64)
+        cost = t.empty((B,), **f64)
+        status = t.empty((B,), dtype=t.int32, device=self.device)
+        _check(self.lib.eepacc_qp_solve_batched(self.h, B, nV, nC, H.data_ptr(), g.data_ptr(), A_cm.data_ptr(),
+                                                ptr(lba), ptr(uba), ptr(lbx), ptr(ubx), ptr(x0), x.data_ptr(),
+                                                cost.data_ptr(), status.data_ptr(), self._stream()))
+        return x, cost, status
 
     def last_iterations(self, B):
         it = np.zeros(B, dtype=np.int32)

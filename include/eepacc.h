@@ -37,6 +37,8 @@ extern "C" {
 #define EEPACC_ENOTSUP      -4   /* setting valid in the reference but not built here  */
 
 #define EEPACC_MAX_HORIZON   63  /* N_hor upper limit of the HIP kernels               */
+#define EEPACC_QP_MAX_NV    384  /* dense QP operator: variables                       */
+#define EEPACC_QP_MAX_NC   2048  /* dense QP operator: rows of A                       */
 
 /* Vehicle constants: the struct V returned by SetVehicleParameters()
  * (ABO/Functions/Settings/SetVehicleParameters.m:12-133; ORIG/ holds the BMW i3 values). */
@@ -144,6 +146,23 @@ int  eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps,
                       const double* s0, const double* v0, const double* a_minus1,
                       const double* s_tv, const double* v_tv,
                       double* traj, int32_t* status, void* stream);
+
+/* B3 -- dense QP operator: the call
+ *   sol = QPsolver('h',H,'g',c,'a',G,'lbx',z_lb,'ubx',z_ub,'lba',g_lb,'uba',g_ub)
+ * of ABO/RunOpt_ABMPC.m:252 and ABO/RunOpt_FBMPC.m:278 (CasADi conic, CAS/+casadi/conic.m:951-966)
+ * for B independent problems of one shape:  min 1/2 x'Hx + g'x  s.t. lba <= Ax <= uba,
+ * lbx <= x <= ubx.  Device arrays, instance-major: H [B][nV*nV] (symmetrised internally, so
+ * row- or column-major), g [B][nV], A [B][nV][nC] = COLUMN-major nC x nV as MATLAB/CasADi hold
+ * it, lba/uba [B][nC], lbx/ubx [B][nV]; +-inf entries and NULL bound arrays mean "absent".
+ * x0 [B][nV] or NULL: proximal centre / initial guess (the reference passes none for AB and
+ * hot-starts implicitly).  Outputs x [B][nV], cost [B] (may be NULL), status [B] (may be
+ * NULL; 0 = KKT point verified, 1 = not converged).  H may be singular PSD or indefinite
+ * (FB): a proximal term is added internally and removed by the final exact KKT solve. */
+int  eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC,
+                             const double* H, const double* g, const double* A,
+                             const double* lba, const double* uba,
+                             const double* lbx, const double* ubx, const double* x0,
+                             double* x, double* cost, int32_t* status, void* stream);
 
 /* Same two operators for the force-based MPC (ABO/RunOpt_FBMPC.m:161-331).  v_prev, Fm_prev,
  * Fb_prev are the previous step's state/controls (ABO/RunOpt_FBMPC.m:188-191). */
