@@ -8,6 +8,7 @@
 #include <vector>
 #include "eepacc_device.h"
 #include "eepacc_qp_dense.h"
+#include "eepacc_fb.h"
 #include "../../include/eepacc.h"
 
 namespace eepacc {
@@ -49,6 +50,13 @@ struct eepacc_handle {
     int carry_B = 0;
     double* d_qp_ws = nullptr;               // workspace of the dense QP operator
     size_t qp_ws_doubles = 0;
+    // FBMPC state (allocated on first use)
+    int fb_B = 0, fb_chunk = 0;
+    int fb_k_done = 0;
+    double *fb_H = nullptr, *fb_g = nullptr, *fb_A = nullptr, *fb_lba = nullptr, *fb_uba = nullptr;   // [fb_chunk]
+    double *fb_x = nullptr, *fb_x0 = nullptr, *fb_cost = nullptr, *fb_meas = nullptr, *fb_carry = nullptr;   // [fb_B]
+    double *fb_A22 = nullptr, *fb_D2 = nullptr;
+    int32_t* fb_qpstat = nullptr;
 };
 
 extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
@@ -134,6 +142,9 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     C.stopRefDist = S->stopRefDist; C.stopRefVelSlope = S->stopRefVelSlope; C.stopVel = S->stopVel;
     C.TLstopVel = S->TLstopVel; C.TLStopRegionSize = S->TLStopRegionSize;
     for (int i = 0; i < 21; ++i) C.b5[i] = S->b_fifthOrder[i];
+    for (int i = 0; i < 7; ++i) C.fb_w[i] = S->W_FB[i];
+    for (int i = 0; i < 6; ++i) C.b_quadr[i] = S->b_quadr[i];
+    C.FBuseTaylor = S->FBuseTaylor ? 1 : 0;
     // a-space Hessian of the condensed objective (step invariant for AB):
     //   H = 2 cq Sv'Sv + 2 w_a I + jerk tridiagonal (CreateQP_AB.m:162-180 through Psi)
     std::vector<long double> H((size_t)N * N, 0.0L);
@@ -202,6 +213,15 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     return EEPACC_OK;
 }
 
+static void fb_free(eepacc_handle* h) {
+    double** ptrs[] = {&h->fb_H, &h->fb_g, &h->fb_A, &h->fb_lba, &h->fb_uba, &h->fb_x, &h->fb_x0, &h->fb_cost,
+                       &h->fb_meas, &h->fb_carry, &h->fb_A22, &h->fb_D2};
+    for (double** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (h->fb_qpstat) (void)hipFree(h->fb_qpstat);
+    h->fb_qpstat = nullptr;
+    h->fb_B = 0; h->fb_chunk = 0;
+}
+
 extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -213,6 +233,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_done) (void)hipFree(h->d_done);
     if (h->d_qp_ws) (void)hipFree(h->d_qp_ws);
+    fb_free(h);
     delete h;
 }
 
@@ -221,6 +242,8 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemset(h->d_codes, 0, (size_t)h->max_batch * 64 * sizeof(unsigned long long)));
     h->k_done = 0; h->carry_B = 0;
+    h->fb_k_done = 0;
+    if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));
     return EEPACC_OK;
 }
 
@@ -340,17 +363,144 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
     return EEPACC_OK;
 }
 
-// FBMPC (ABO/RunOpt_FBMPC.m) -- declared in the ABI, HIP kernels not built in this round.
-extern "C" int eepacc_fb_step(eepacc_handle*, int, const double*, const double*, const double*, const double*,
-                              const double*, const double*, const double*, const double*, const double*,
-                              const double*, double*, double*, double*, int32_t*, void*) {
-    return fail(EEPACC_ENOTSUP, "eepacc_fb_step: FBMPC kernels are not built yet");
+// FBMPC (ABO/RunOpt_FBMPC.m:161-331): build kernel -> dense QP operator -> extraction, per step.
+static int fb_prepare(eepacc_handle* h, int B) {
+    const int N = h->cfg.N;
+    const size_t nV = 6 * (size_t)N, nC = 26 * (size_t)N + 2;
+    if (h->cfg.paramEstSetting != 0 && h->cfg.paramEstSetting != 1) return fail(EEPACC_ENOTSUP, "FBMPC: paramEstSetting 2 is not built");
+    if (nV > EEPACC_QP_MAX_NV || nC > EEPACC_QP_MAX_NC || eepacc_qp_dense_lds_bytes((int)nV, (int)nC) > 160 * 1024)
+        return fail(EEPACC_ENOTSUP, "FBMPC: horizon too long for the dense QP operator");
+    if (B <= h->fb_B) return EEPACC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    fb_free(h);
+    // the dense QP data is held for a chunk of instances at a time (about 16 GB at most)
+    const size_t per = (nV * nV + nC * nV + nV + 2 * nC) * sizeof(double);
+    size_t chunk = (size_t)16e9 / per;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)B) chunk = (size_t)B;
+    const size_t nB = (size_t)B;
+    bool ok = hipMalloc(&h->fb_H, chunk * nV * nV * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_g, chunk * nV * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_A, chunk * nC * nV * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_lba, chunk * nC * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_uba, chunk * nC * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_x, nB * nV * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_x0, nB * nV * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_cost, nB * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_meas, 5 * nB * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_carry, 5 * nB * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_A22, nB * N * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_D2, nB * N * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_qpstat, nB * sizeof(int32_t)) == hipSuccess;
+    if (!ok) { fb_free(h); return fail(EEPACC_ENOMEM, "FBMPC: device allocation failed"); }
+    HIPCHK(hipMemset(h->fb_x0, 0, nB * nV * sizeof(double)));
+    HIPCHK(hipMemset(h->fb_A22, 0, nB * N * sizeof(double)));
+    HIPCHK(hipMemset(h->fb_D2, 0, nB * N * sizeof(double)));
+    h->fb_B = B; h->fb_chunk = (int)chunk;
+    h->fb_k_done = 0;
+    return EEPACC_OK;
 }
-extern "C" int eepacc_run_fbmpc(eepacc_handle*, int, int, const double*, const double*, const double*,
-                                const double*, const double*, double*, int32_t*, void*) {
-    return fail(EEPACC_ENOTSUP, "eepacc_run_fbmpc: FBMPC kernels are not built yet");
+
+// one FBMPC step for B instances; in[] as eepacc_fb_args documents for the mode
+static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const double* v, const double* a_prev,
+                       const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                       double* out, double* s_pred, double* v_pred, int32_t* status, hipStream_t stream) {
+    const int N = h->cfg.N, nV = 6 * N, nC = 26 * N + 2;
+    for (int b0 = 0; b0 < B; b0 += h->fb_chunk) {
+        const int nb = (B - b0 < h->fb_chunk) ? B - b0 : h->fb_chunk;
+        eepacc::eepacc_fb_args a;
+        a.cfg = h->d_cfg; a.B = B; a.k_step = h->fb_k_done; a.b0 = b0; a.nb = nb; a.mode = mode;
+        a.s = s; a.v = v; a.a_prev = a_prev; a.t0 = t0; a.s_tv = s_tv; a.v_tv = v_tv; a.a_tv_prev = a_tv_prev;
+        a.carry = h->fb_carry; a.A22 = h->fb_A22; a.D2 = h->fb_D2;
+        a.H = h->fb_H; a.g = h->fb_g; a.A = h->fb_A; a.lba = h->fb_lba; a.uba = h->fb_uba; a.meas = h->fb_meas;
+        HIPCHK(eepacc::launch_fb_build(a, N, stream));
+        int grid = nb < 2 * h->num_cus ? nb : 2 * h->num_cus;
+        int rc = qp_workspace(h, grid, nV);
+        if (rc != EEPACC_OK) return rc;
+        eepacc_qp_args q;
+        q.B = nb; q.nV = nV; q.nC = nC; q.H = h->fb_H; q.g = h->fb_g; q.A = h->fb_A; q.lba = h->fb_lba; q.uba = h->fb_uba;
+        q.lbx = nullptr; q.ubx = nullptr;
+        q.x0 = h->fb_x0 + (size_t)b0 * nV; q.x = h->fb_x + (size_t)b0 * nV; q.cost = h->fb_cost + b0;
+        q.status = h->fb_qpstat + b0; q.iters = (B <= h->max_batch) ? h->d_iters + b0 : nullptr;
+        q.ws = h->d_qp_ws; q.ws_stride = eepacc_qp_dense_ws_doubles(nV); q.rho_rel = 0.0; q.max_prox = 0;
+        HIPCHK(eepacc_qp_dense_launch(q, grid, stream));
+    }
+    eepacc::eepacc_fb_apply_args p;
+    p.cfg = h->d_cfg; p.B = B; p.x = h->fb_x; p.cost = h->fb_cost; p.qp_status = h->fb_qpstat; p.meas = h->fb_meas;
+    p.A22 = h->fb_A22; p.D2 = h->fb_D2; p.out = out; p.s_pred = s_pred; p.v_pred = v_pred; p.status = status;
+    p.carry = mode == 1 ? h->fb_carry : nullptr;
+    HIPCHK(eepacc::launch_fb_apply(p, stream));
+    // the solution is the proximal centre / initial guess of the next step
+    HIPCHK(hipMemcpyAsync(h->fb_x0, h->fb_x, (size_t)B * nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    h->fb_k_done += 1;
+    h->last_B = B;
+    return EEPACC_OK;
 }
-extern "C" int eepacc_run_fbmpc_host(eepacc_handle*, int, int, const double*, const double*, const double*,
-                                     const double*, const double*, double*, int32_t*) {
-    return fail(EEPACC_ENOTSUP, "eepacc_run_fbmpc_host: FBMPC kernels are not built yet");
+
+extern "C" int eepacc_fb_step(eepacc_handle* h, int B, const double* s, const double* v, const double* v_prev,
+                              const double* a_prev, const double* Fm_prev, const double* Fb_prev, const double* t0,
+                              const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                              double* out, double* s_pred, double* v_pred, int32_t* status, void* stream) {
+    (void)v_prev; (void)Fm_prev; (void)Fb_prev;   // accepted and unused, as in CreateQP_FB.m:1 (inputs v_minus1, Fm_minus1, Fb_minus1)
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 0 || B > h->max_batch) return fail(EEPACC_EINVAL, "B exceeds max_batch of the handle");
+    if (B == 0) return EEPACC_OK;
+    if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out)
+        return fail(EEPACC_EINVAL, "eepacc_fb_step: NULL buffer");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = fb_prepare(h, B);
+    if (rc != EEPACC_OK) return rc;
+    return fb_one_step(h, B, 0, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, out, s_pred, v_pred, status, (hipStream_t)stream);
+}
+
+extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                const double* a_minus1, const double* s_tv, const double* v_tv,
+                                double* traj, int32_t* status, void* stream) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 0 || B > h->max_batch || n_steps < 0) return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: bad B / n_steps");
+    if (B == 0 || n_steps == 0) return EEPACC_OK;
+    if (!s0 || !v0 || !a_minus1 || !s_tv || !v_tv || !traj || !status)
+        return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: NULL buffer");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->fb_k_done > 0 && B != h->last_B)
+        return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: B changed while resuming; call eepacc_reset first");
+    int rc = fb_prepare(h, B);
+    if (rc != EEPACC_OK) return rc;
+    for (int kk = 0; kk < n_steps; ++kk) {
+        rc = fb_one_step(h, B, 1, s0, v0, a_minus1, nullptr, s_tv + (size_t)kk * B, v_tv + (size_t)kk * B, nullptr,
+                         traj + (size_t)kk * EEPACC_OUT_N * B, nullptr, nullptr, status + (size_t)kk * B,
+                         (hipStream_t)stream);
+        if (rc != EEPACC_OK) return rc;
+    }
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_run_fbmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                     const double* a_minus1, const double* s_tv, const double* v_tv,
+                                     double* traj, int32_t* status) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 1 || B > h->max_batch || n_steps < 1) return fail(EEPACC_EINVAL, "bad B / n_steps");
+    HIPCHK(hipSetDevice(h->device));
+    double *d_in = nullptr, *d_tv = nullptr, *d_traj = nullptr;
+    int32_t* d_status = nullptr;
+    const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
+    HIPCHK(hipMalloc(&d_in, 3 * nB * sizeof(double)));
+    HIPCHK(hipMalloc(&d_tv, 2 * nT * sizeof(double)));
+    HIPCHK(hipMalloc(&d_traj, nT * EEPACC_OUT_N * sizeof(double)));
+    HIPCHK(hipMalloc(&d_status, nT * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(d_in, s0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_in + nB, v0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    int rc = eepacc_reset(h);
+    if (rc == EEPACC_OK)
+        rc = eepacc_run_fbmpc(h, B, n_steps, d_in, d_in + nB, d_in + 2 * nB, d_tv, d_tv + nT, d_traj, d_status, nullptr);
+    if (rc == EEPACC_OK) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(traj, d_traj, nT * EEPACC_OUT_N * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(status, d_status, nT * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_in); (void)hipFree(d_tv); (void)hipFree(d_traj); (void)hipFree(d_status);
+    return rc;
 }

@@ -54,6 +54,10 @@ struct DevCfg {
     double TLLoc[kMaxTL * 4];
     double stopRefDist, stopRefVelSlope, stopVel, TLstopVel, TLStopRegionSize;
     double b5[21];                // fifth-order power surface
+    // FBMPC (ABO/Settings.m:31-46, 229): weights [w_P,w_a,w_j,w_v,w_h,w_s,w_f], quadratic power fit
+    double fb_w[7];
+    double b_quadr[6];
+    int32_t FBuseTaylor, fb_pad;
     const double* Hinv;           // device, [N][N] row-major, inverse of the a-space Hessian
 };
 

@@ -49,6 +49,9 @@ def load_library() -> C.CDLL:
     lib.eepacc_run_abmpc_host.argtypes = [vp, C.c_int, C.c_int] + [c_double_p] * 5 + [c_double_p, ip]
     lib.eepacc_postprocess.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, vp]
     lib.eepacc_last_iterations.argtypes = [vp, C.c_int, ip]
+    lib.eepacc_fb_step.argtypes = [vp, C.c_int] + [dp] * 10 + [dp, dp, dp, dp, vp]
+    lib.eepacc_run_fbmpc.argtypes = [vp, C.c_int, C.c_int] + [dp] * 5 + [dp, dp, vp]
+    lib.eepacc_run_fbmpc_host.argtypes = [vp, C.c_int, C.c_int] + [c_double_p] * 5 + [c_double_p, ip]
     lib.eepacc_qp_solve_batched.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [dp] * 8 + [dp, dp, dp, vp]
     _lib = lib
     return lib
@@ -138,6 +141,39 @@ class Engine:
             traj = t.empty((n_steps, OUT_N, B), dtype=t.float64, device=self.device)
             status = t.empty((n_steps, B), dtype=t.int32, device=self.device)
         _check(self.lib.eepacc_run_abmpc(self.h, B, n_steps, *[x.data_ptr() for x in ins], s_tv.data_ptr(),
+                                         v_tv.data_ptr(), traj.data_ptr(), status.data_ptr(), self._stream()))
+        return traj, status
+
+    # FBMPC: same two operators (ABO/RunOpt_FBMPC.m:161-331) -----------------------------------
+    def fb_step(self, s, v, v_prev, a_prev, Fm_prev, Fb_prev, t0, s_tv, v_tv, a_tv_prev, want_pred: bool = True):
+        t = self.torch
+        B = int(t.as_tensor(s).numel())
+        ins = [self._d(x, B) for x in (s, v, v_prev, a_prev, Fm_prev, Fb_prev, t0, s_tv, v_tv, a_tv_prev)]
+        out = t.empty((OUT_N, B), dtype=t.float64, device=self.device)
+        sp = t.empty((self.N + 1, B), dtype=t.float64, device=self.device) if want_pred else None
+        vp = t.empty((self.N + 1, B), dtype=t.float64, device=self.device) if want_pred else None
+        status = t.empty((B,), dtype=t.int32, device=self.device)
+        _check(self.lib.eepacc_fb_step(self.h, B, *[x.data_ptr() for x in ins], out.data_ptr(),
+                                       sp.data_ptr() if want_pred else None,
+                                       vp.data_ptr() if want_pred else None, status.data_ptr(), self._stream()))
+        return out, sp, vp, status
+
+    def run_fbmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False, out=None):
+        """Closed-loop FBMPC; arguments and results as run_abmpc."""
+        t = self.torch
+        if not resume:
+            self.reset()
+        s_tv = t.as_tensor(s_tv, dtype=t.float64, device=self.device).contiguous()
+        v_tv = t.as_tensor(v_tv, dtype=t.float64, device=self.device).contiguous()
+        n_steps, B = s_tv.shape
+        ins = [self._d(x, B) for x in (s0, v0, a_minus1)]
+        if out is not None:
+            traj, status = out[0][:n_steps], out[1][:n_steps]
+            assert traj.shape == (n_steps, OUT_N, B) and traj.is_contiguous() and status.is_contiguous()
+        else:
+            traj = t.empty((n_steps, OUT_N, B), dtype=t.float64, device=self.device)
+            status = t.empty((n_steps, B), dtype=t.int32, device=self.device)
+        _check(self.lib.eepacc_run_fbmpc(self.h, B, n_steps, *[x.data_ptr() for x in ins], s_tv.data_ptr(),
                                          v_tv.data_ptr(), traj.data_ptr(), status.data_ptr(), self._stream()))
         return traj, status
 
