@@ -144,3 +144,24 @@ def test_fb_final_step_dense_H_G(tree):
     assert r["G"].shape == G["G"].shape == (522, 120)
     assert np.abs(r["G"] - G["G"]).max() < 1e-12
     assert np.abs(r["H"] - G["H"]).max() < 1e-11 * np.abs(G["H"]).max()
+
+
+@pytest.mark.parametrize("tree", TREES)
+def test_fb_closed_loop_871_steps(tree):
+    """Oracle FBMPC closed loop against the saved FB solution.  k = 0 is the degenerate force split
+    of SURVEY.md section 8c (only Fm+Fb is determined), so Fm/Fb are compared as their sum; the ABO
+    golden has two more such steps, which bounds its tolerances."""
+    OPT, V, s_tv, v_tv = make_case(tree, 20)
+    G = load_golden(f"{tree.lower()}_fbmpc")
+    orc = Oracle(OPT, V)
+    ref, st, it = orc.run("fb", 871, 0.0, 0.0, 0.0, s_tv, v_tv)
+    tol = 2e-6 if tree == "ABO" else 1e-9
+    assert st.sum() <= 3 and st[0] == 1
+    for n, g in (("s", "s_opt"), ("v", "v_opt"), ("xi_v", "xi_v_opt"), ("xi_h", "xi_h_opt"), ("xi_s", "xi_s_opt"),
+                 ("xi_f", "xi_f_opt")):
+        assert np.abs(ref[:, OUT[n]] - G[g]).max() < tol, n
+    assert np.abs(ref[1:, OUT["a"]] - G["a_opt"][1:]).max() < tol
+    F = ref[:, OUT["Fm"]] + ref[:, OUT["Fb"]]
+    assert np.abs(F - G["Fm_opt"] - G["Fb_opt"]).max() < (1e-2 if tree == "ABO" else 1e-6)
+    if tree == "ORIG":
+        assert np.abs(ref[1:, OUT["Fm"]] - G["Fm_opt"][1:]).max() < 1e-6
