@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct eepacc_handle {
     int carry_B = 0;
     double* d_qp_ws = nullptr;               // workspace of the dense QP operator
     size_t qp_ws_doubles = 0;
+    int* d_qp_counter = nullptr;
     // FBMPC state (allocated on first use)
     int fb_B = 0, fb_chunk = 0;
     int fb_k_done = 0;
@@ -203,6 +205,7 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMemset(h->d_carry, 0, (size_t)max_batch * 6 * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(int)));
     HIPCHK(hipMalloc(&h->d_done, sizeof(int) * (size_t)max_batch));
+    HIPCHK(hipMalloc(&h->d_qp_counter, sizeof(int)));
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -233,6 +236,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_done) (void)hipFree(h->d_done);
     if (h->d_qp_ws) (void)hipFree(h->d_qp_ws);
+    if (h->d_qp_counter) (void)hipFree(h->d_qp_counter);
     fb_free(h);
     delete h;
 }
@@ -330,6 +334,14 @@ extern "C" int eepacc_last_iterations(eepacc_handle* h, int B, int32_t* iters_ho
 }
 
 // B3 -- dense QP operator (ABO/RunOpt_ABMPC.m:252)
+// persistent workgroups of the dense QP kernel per compute unit (EEPACC_QP_WGS_PER_CU overrides)
+static int qp_grid(const eepacc_handle* h, int B) {
+    int per_cu = 2;
+    if (const char* e = getenv("EEPACC_QP_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    const int g = per_cu * h->num_cus;
+    return B < g ? B : g;
+}
+
 static int qp_workspace(eepacc_handle* h, int grid, int nV) {
     size_t need = (size_t)grid * eepacc_qp_dense_ws_doubles(nV);
     if (need > h->qp_ws_doubles) {
@@ -352,13 +364,15 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
     if (!H || !g || !x || (nC > 0 && !A)) return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: NULL buffer");
     if (eepacc_qp_dense_lds_bytes(nV, nC) > 160 * 1024) return fail(EEPACC_EINVAL, "eepacc_qp_solve_batched: problem does not fit LDS");
     HIPCHK(hipSetDevice(h->device));
-    int grid = B < 2 * h->num_cus ? B : 2 * h->num_cus;
+    int grid = qp_grid(h, B);
     int rc = qp_workspace(h, grid, nV);
     if (rc != EEPACC_OK) return rc;
     eepacc_qp_args a;
     a.B = B; a.nV = nV; a.nC = nC; a.H = H; a.g = g; a.A = A; a.lba = lba; a.uba = uba; a.lbx = lbx; a.ubx = ubx;
     a.x0 = x0; a.x = x; a.cost = cost; a.status = status; a.iters = (B <= h->max_batch) ? h->d_iters : nullptr;
     a.ws = h->d_qp_ws; a.ws_stride = eepacc_qp_dense_ws_doubles(nV); a.rho_rel = 0.0; a.max_prox = 0;
+    a.counter = h->d_qp_counter;
+    HIPCHK(hipMemsetAsync(h->d_qp_counter, 0, sizeof(int), (hipStream_t)stream));
     HIPCHK(eepacc_qp_dense_launch(a, grid, (hipStream_t)stream));
     return EEPACC_OK;
 }
@@ -414,7 +428,7 @@ static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const
         a.carry = h->fb_carry; a.A22 = h->fb_A22; a.D2 = h->fb_D2;
         a.H = h->fb_H; a.g = h->fb_g; a.A = h->fb_A; a.lba = h->fb_lba; a.uba = h->fb_uba; a.meas = h->fb_meas;
         HIPCHK(eepacc::launch_fb_build(a, N, stream));
-        int grid = nb < 2 * h->num_cus ? nb : 2 * h->num_cus;
+        int grid = qp_grid(h, nb);
         int rc = qp_workspace(h, grid, nV);
         if (rc != EEPACC_OK) return rc;
         eepacc_qp_args q;
@@ -423,6 +437,8 @@ static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const
         q.x0 = h->fb_x0 + (size_t)b0 * nV; q.x = h->fb_x + (size_t)b0 * nV; q.cost = h->fb_cost + b0;
         q.status = h->fb_qpstat + b0; q.iters = (B <= h->max_batch) ? h->d_iters + b0 : nullptr;
         q.ws = h->d_qp_ws; q.ws_stride = eepacc_qp_dense_ws_doubles(nV); q.rho_rel = 0.0; q.max_prox = 0;
+        q.counter = h->d_qp_counter;
+        HIPCHK(hipMemsetAsync(h->d_qp_counter, 0, sizeof(int), stream));
         HIPCHK(eepacc_qp_dense_launch(q, grid, stream));
     }
     eepacc::eepacc_fb_apply_args p;

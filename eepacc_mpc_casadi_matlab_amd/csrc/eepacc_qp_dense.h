@@ -11,6 +11,7 @@ struct eepacc_qp_args {
     const double *H, *g, *A, *lba, *uba, *lbx, *ubx, *x0;   // device, instance-major
     double *x, *cost;
     int32_t *status, *iters;
+    int* counter;          // device int, zeroed before the launch (work distribution)
     double* ws;            // grid * ws_stride doubles
     size_t ws_stride;
     double rho_rel;        // <= 0: 1e-7

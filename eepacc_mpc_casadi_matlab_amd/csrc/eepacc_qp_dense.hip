@@ -21,6 +21,15 @@
 
 #include "eepacc_qp_dense.h"
 
+#ifdef EEPACC_QP_TIMING
+__device__ long long g_qp_prof[16];
+#define TIC(var) long long var = wall_clock64()
+#define TOC(var, slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_qp_prof[slot] += wall_clock64() - var; } while (0)
+#else
+#define TIC(var)
+#define TOC(var, slot)
+#endif
+
 namespace {
 
 constexpr int QT = 256;
@@ -38,7 +47,7 @@ struct Lds {
 };
 
 struct Ws {              // per-workgroup global workspace
-    double *Hs, *J0T, *JT, *R, *K;      // n^2, n^2, n^2, n^2, (2n+1)^2 ; L aliases K
+    double *Hs, *J0T, *JT, *R, *R2, *T, *T2, *K;   // n^2 each, K (2n+2)^2 ; L aliases K.  T = R^-1 (column-major)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -129,25 +138,43 @@ __device__ double con_value(const Prob& P, int c, const double* x, const Lds& S)
     return sgn * s - b;
 }
 
-// ax = A x
+// ax = A x  (thread per row; loads issued eight at a time, summation order j = 0..n-1)
 __device__ void rows_times(const Prob& P, const double* x, double* ax) {
+    const size_t ld = (size_t)P.nC;
     for (int i = threadIdx.x; i < P.nC; i += QT) {
         double s = 0.0;
         const double* a = P.A + i;
-        for (int j = 0; j < P.n; ++j) s += a[(size_t)j * P.nC] * x[j];
+        int j = 0;
+        for (; j + 8 <= P.n; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a[(size_t)(j + u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u] * x[j + u];
+        }
+        for (; j < P.n; ++j) s += a[(size_t)j * ld] * x[j];
         ax[i] = s;
     }
     __syncthreads();
 }
 
-// dv[j] = sum_k M[j][k] v[k]  (row-major n x n in global, one wavefront per row)
+// dv[j] = sum_k M[j][k] v[k]  (row-major n x n in global, one wavefront per row, four rows in flight)
 __device__ void rowdot(const double* M, int n, const double* v, double* out) {
-    for (int j = wave_id(); j < n; j += QW) {
-        const double* row = M + (size_t)j * n;
-        double s = 0.0;
-        for (int k = lane_id(); k < n; k += 64) s += row[k] * v[k];
-        s = wave_sum(s);
-        if (lane_id() == 0) out[j] = s;
+    for (int j0 = 4 * wave_id(); j0 < n; j0 += 4 * QW) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = lane_id(); k < n; k += 64) {
+            double m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = (j0 + u < n) ? M[(size_t)(j0 + u) * n + k] : 0.0;
+            const double vk = v[k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += m[u] * vk;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double r = wave_sum(s[u]);
+            if (lane_id() == 0 && j0 + u < n) out[j0 + u] = r;
+        }
     }
     __syncthreads();
 }
@@ -156,7 +183,15 @@ __device__ void rowdot(const double* M, int n, const double* v, double* out) {
 __device__ void coldot(const double* M, int n, int j0, const double* c, double* out, double scale) {
     for (int k = threadIdx.x; k < n; k += QT) {
         double s = 0.0;
-        for (int j = j0; j < n; ++j) s += M[(size_t)j * n + k] * c[j];
+        int j = j0;
+        for (; j + 8 <= n; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = M[(size_t)(j + u) * n + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u] * c[j + u];
+        }
+        for (; j < n; ++j) s += M[(size_t)j * n + k] * c[j];
         out[k] = scale * s;
     }
     __syncthreads();
@@ -175,10 +210,9 @@ __device__ int chol_lower(double* L, int n, const Lds& S) {
             S.fcol[i] = v;
         }
         __syncthreads();
-        const int m = n - j - 1;
-        for (int idx = threadIdx.x; idx < m * m; idx += QT) {
-            int i = j + 1 + idx / m, k = j + 1 + idx % m;
-            if (k <= i) L[(size_t)i * n + k] -= S.fcol[i] * S.fcol[k];
+        for (int i = j + 1 + wave_id(); i < n; i += QW) {
+            const double fi = S.fcol[i];
+            for (int k = j + 1 + lane_id(); k <= i; k += 64) L[(size_t)i * n + k] -= fi * S.fcol[k];
         }
         __syncthreads();
     }
@@ -230,11 +264,18 @@ __device__ double lu_factor(double* K, int Nk, const Lds& S) {
             S.fcol[i] = f;
         }
         __syncthreads();
-        const int m = Nk - k - 1;
-        for (int idx = threadIdx.x; idx < m * m; idx += QT) {
-            int i = k + 1 + idx / m, j = k + 1 + idx % m;
-            double f = S.fcol[i];
-            if (f != 0.0) K[(size_t)i * Nk + j] -= f * K[(size_t)k * Nk + j];
+        {
+            // pivot row in registers (up to 12 entries per lane), rows of the trailing block over the waves
+            double pr[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) { int j = k + 1 + lane_id() + 64 * u; pr[u] = j < Nk ? K[(size_t)k * Nk + j] : 0.0; }
+            for (int i = k + 1 + wave_id(); i < Nk; i += QW) {
+                const double f = S.fcol[i];
+                if (f == 0.0) continue;
+                double* ri = K + (size_t)i * Nk;
+#pragma unroll
+                for (int u = 0; u < 12; ++u) { int j = k + 1 + lane_id() + 64 * u; if (j < Nk) ri[j] -= f * pr[u]; }
+            }
         }
         __syncthreads();
     }
@@ -271,12 +312,12 @@ __device__ int kkt_solve(const Prob& P, const Ws& W, const Lds& S, double rho, c
     const int n = P.n, Nk = n + q;
     double* K = W.K;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < Nk * Nk; idx += QT) {
-        int i = idx / Nk, j = idx % Nk;
-        double v = 0.0;
-        if (i < n && j < n) v = W.Hs[(size_t)i * n + j] + (i == j ? rho : 0.0);
-        K[idx] = v;
-    }
+    for (int i = wave_id(); i < Nk; i += QW)
+        for (int j = lane_id(); j < Nk; j += 64) {
+            double v = 0.0;
+            if (i < n && j < n) v = W.Hs[(size_t)i * n + j] + (i == j ? rho : 0.0);
+            K[(size_t)i * Nk + j] = v;
+        }
     __syncthreads();
     for (int c = 0; c < q; ++c) {
         int row; double sgn, b;
@@ -390,83 +431,174 @@ __device__ int gi_add(const Ws& W, const Lds& S, int n, int q) {
         t *= beta;
         for (int j = q; j < n; ++j) W.JT[(size_t)j * n + k] -= t * d[j];
     }
-    for (int i = threadIdx.x; i <= q; i += QT) W.R[(size_t)q * n + i] = (i < q) ? d[i] : alpha;
+    for (int i = threadIdx.x; i <= q; i += QT) {
+        W.R[(size_t)q * n + i] = (i < q) ? d[i] : alpha;
+        // inverse of [R d1; 0 alpha] : last column (-R^-1 d1 / alpha ; 1/alpha), and S.r = R^-1 d1
+        W.T[(size_t)q * n + i] = (i < q) ? -S.r[i] / alpha : 1.0 / alpha;
+    }
     __syncthreads();
     return 0;
 }
 
-// drop active constraint at position l (q = count before the drop)
-__device__ void gi_drop(const Ws& W, const Lds& S, int n, int q, int l) {
-    __syncthreads();
-    // shift columns of R and the act/u lists
-    for (int j = l; j < q - 1; ++j) {
-        for (int i = threadIdx.x; i <= j + 1; i += QT) W.R[(size_t)j * n + i] = W.R[(size_t)(j + 1) * n + i];
+// one chain of plane rotations along a strided vector: v[j], v[j+1] <- rot_j, j = l .. qn-1
+// (v[j] = base[j*ld]).  The right-hand elements are loaded four steps ahead of their use.
+__device__ __forceinline__ void rot_chain(double* base, size_t ld, int l, int qn, const double* Cs, const double* Sn,
+                                          bool keep_last) {
+    double x = base[(size_t)l * ld];
+    int j = l;
+    for (; j + 4 <= qn; j += 4) {
+        double y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = base[(size_t)(j + 1 + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double c = Cs[j + u], sn = Sn[j + u];
+            base[(size_t)(j + u) * ld] = c * x + sn * y[u];
+            x = -sn * x + c * y[u];
+        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int j = l; j < q - 1; ++j) { S.act[j] = S.act[j + 1]; S.u[j] = S.u[j + 1]; }
-        S.u[q - 1] = S.u[q];
-        S.u[q] = 0.0;
+    for (; j < qn; ++j) {
+        const double y = base[(size_t)(j + 1) * ld];
+        const double c = Cs[j], sn = Sn[j];
+        base[(size_t)j * ld] = c * x + sn * y;
+        x = -sn * x + c * y;
     }
+    if (keep_last) base[(size_t)qn * ld] = x;
+}
+
+// drop active constraint at position l (q = count before the drop).
+// Wavefront 0 re-triangularises R (column l removed) with the row pair it works on held in
+// registers -- no barrier inside the chain -- and records the rotations; meanwhile the other
+// wavefronts copy the untouched part of R and strip row l from T = R^-1.  Then every thread applies
+// the recorded chain to one column of J (a row pair of JT per step) or one row of T.
+__device__ void gi_drop(Ws& W, const Lds& S, int n, int q, int l) {
     __syncthreads();
     const int qn = q - 1;
-    for (int j = l; j < qn; ++j) {
-        double a = W.R[(size_t)j * n + j], b = W.R[(size_t)j * n + j + 1];
-        __syncthreads();
-        if (b == 0.0) continue;
-        double h = hypot(a, b), c = a / h, s = b / h;
-        for (int k = j + threadIdx.x; k < qn; k += QT) {
-            double x = W.R[(size_t)k * n + j], y = W.R[(size_t)k * n + j + 1];
-            W.R[(size_t)k * n + j] = c * x + s * y;
-            W.R[(size_t)k * n + j + 1] = -s * x + c * y;
+    double* Cs = S.res;
+    double* Sn = S.fcol;
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        double carry[6], y[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int kk = l + lane + 64 * u;
+            carry[u] = kk < qn ? W.R[(size_t)(kk + 1) * n + l] : 0.0;
+            y[u] = (kk < qn && l < qn) ? W.R[(size_t)(kk + 1) * n + l + 1] : 0.0;
         }
-        for (int k = threadIdx.x; k < n; k += QT) {
-            double x = W.JT[(size_t)j * n + k], y = W.JT[(size_t)(j + 1) * n + k];
-            W.JT[(size_t)j * n + k] = c * x + s * y;
-            W.JT[(size_t)(j + 1) * n + k] = -s * x + c * y;
+        for (int j = l; j < qn; ++j) {
+            double yn[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int kk = l + lane + 64 * u;
+                yn[u] = (kk < qn && kk >= j + 1 && j + 1 < qn) ? W.R[(size_t)(kk + 1) * n + j + 2] : 0.0;
+            }
+            const int oj = j - l, ol = oj & 63, ou = oj >> 6;
+            double av = ou == 0 ? carry[0] : ou == 1 ? carry[1] : ou == 2 ? carry[2] : ou == 3 ? carry[3] : ou == 4 ? carry[4] : carry[5];
+            double bv = ou == 0 ? y[0] : ou == 1 ? y[1] : ou == 2 ? y[2] : ou == 3 ? y[3] : ou == 4 ? y[4] : y[5];
+            av = __shfl(av, ol); bv = __shfl(bv, ol);
+            double c = 1.0, sn = 0.0;
+            if (bv != 0.0) { const double h = hypot(av, bv); c = av / h; sn = bv / h; }
+            if (lane == 0) { Cs[j] = c; Sn[j] = sn; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int kk = l + lane + 64 * u;
+                if (kk < qn && kk >= j) {
+                    W.R2[(size_t)kk * n + j] = c * carry[u] + sn * y[u];
+                    carry[u] = -sn * carry[u] + c * y[u];
+                }
+                y[u] = yn[u];
+            }
         }
-        __syncthreads();
+    } else {
+        const int t = threadIdx.x - 64, nt = QT - 64;
+        if (t == 0) {
+            for (int j = l; j < q - 1; ++j) { S.act[j] = S.act[j + 1]; S.u[j] = S.u[j + 1]; }
+            S.u[q - 1] = S.u[q];
+            S.u[q] = 0.0;
+        }
+        const int w = wave_id() - 1, nw = QW - 1;
+        // R2: columns before l unchanged; rows above l of the shifted columns
+        for (int k = w; k < qn; k += nw) {
+            const int ko = k < l ? k : k + 1;
+            const int rows = k < l ? k + 1 : l;
+            for (int i = lane_id(); i < rows; i += 64) W.R2[(size_t)k * n + i] = W.R[(size_t)ko * n + i];
+        }
+        // T2 <- T without row l (the inverse of the re-triangularised R is that matrix with the same
+        // rotations applied to its columns, last column dropped)
+        for (int k = w; k < q; k += nw)
+            for (int i = lane_id(); i < qn; i += 64) {
+                const int io = i < l ? i : i + 1;
+                W.T2[(size_t)k * n + i] = io <= k ? W.T[(size_t)k * n + io] : 0.0;
+            }
+        (void)t; (void)nt;
     }
+    { double* tmp = W.T; W.T = W.T2; W.T2 = tmp; }
+    { double* tmp = W.R; W.R = W.R2; W.R2 = tmp; }
+    __syncthreads();
+    if (l < qn) {
+        for (int task = threadIdx.x; task < n + qn; task += QT) {
+            if (task < n) rot_chain(W.JT + task, (size_t)n, l, qn, Cs, Sn, true);
+            else rot_chain(W.T + (task - n), (size_t)n, l, qn, Cs, Sn, false);
+        }
+    }
+    __syncthreads();
 }
 
 // GI solve of  min 1/2 x'(Hs+rho I)x + gr'x  s.t. list.  Returns 0 ok, 1 infeasible, 2 limit.
-__device__ int gi_solve(const Prob& P, const Ws& W, const Lds& S, double rho, int n_crash_in,
+__device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho, int n_crash_in,
                         int& q_out, int& iters_out, int max_iter) {
     const int n = P.n;
-    int n_crash = n_crash_in;
-restart:
+    Ws W = W_in;
+    const int n_crash = n_crash_in;
     int q = 0, iters = 0, status = 0;
-    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += QT) W.JT[idx] = W.J0T[idx];
     for (int c = threadIdx.x; c < P.m1; c += QT) S.is_act[c] = 0;
     __syncthreads();
-    // x = -G^-1 gr = -J (J' gr)
-    rowdot(W.JT, n, S.gr, S.t);
-    coldot(W.JT, n, 0, S.t, S.x, -1.0);
-    if (n_crash > 0) {
-        // closed-form crash start: the crash variables have no curvature, so with H + rho I they
-        // decouple: x_var = b/coef, multiplier (gr_var + rho x_var)/coef; negative ones are left out
-        int dependent = 0;
+    // x = -G^-1 gr = -J (J' gr) with J = J0 = L^-T
+    rowdot(W.J0T, n, S.gr, S.t);
+    coldot(W.J0T, n, 0, S.t, S.x, -1.0);
+    TIC(t_cr);
+    // Closed-form crash start.  A crash variable has no curvature, so in H + rho I it is decoupled:
+    // row and column `var` of L^-1 hold only the diagonal 1/sqrt(rho).  Hence x_var = b/coef with
+    // multiplier (gr_var + rho x_var)/coef (negative ones are left out), and J' n = coef/sqrt(rho) e_var:
+    // ordering the columns of J so that the crash variables come first makes R diagonal -- the
+    // working set is installed by a row permutation of JT, no reflector needed.
+    int* perm = S.piv;
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < n; ++j) S.t[j] = 0.0;
+        int qq = 0;
         for (int i = 0; i < n_crash; ++i) {
-            int c = S.crash[i];
+            const int c = S.crash[i], var = S.crash[n + i];
             int row; double sgn, b;
             os_get(P, c, row, sgn, b);
-            int var = S.crash[n + i];
-            double coef = row >= 0 ? P.A[(size_t)var * P.nC + row] : 1.0;
-            double xv = b / coef;
-            double uu = (S.gr[var] + rho * xv) / coef;
+            const double coef = row >= 0 ? P.A[(size_t)var * P.nC + row] : 1.0;
+            const double xv = b / coef;
+            const double uu = (S.gr[var] + rho * xv) / coef;
             if (uu < 0.0) continue;
-            get_normal(P, c, S.np);
-            rowdot(W.JT, n, S.np, S.d);
-            if (gi_add(W, S, n, q) != 0) { dependent = 1; break; }
-            if (threadIdx.x == 0) { S.act[q] = c; S.u[q] = uu; S.is_act[c] = 1; S.x[var] = xv; }
-            ++q;
-            __syncthreads();
+            S.act[qq] = c; S.u[qq] = uu; S.is_act[c] = 1; S.x[var] = xv;
+            perm[qq] = var; S.t[var] = 1.0;
+            S.hv[qq] = coef * W.J0T[(size_t)var * n + var];
+            ++qq;
         }
-        if (dependent) { n_crash = 0; goto restart; }
+        S.ired[5] = qq;
+        for (int j = 0; j < n; ++j) if (S.t[j] == 0.0) perm[qq++] = j;
     }
     __syncthreads();
+    q = S.ired[5];
+    for (int r = wave_id(); r < n; r += QW) {
+        const double* src = W.J0T + (size_t)perm[r] * n;
+        double* dst = W.JT + (size_t)r * n;
+        for (int k = lane_id(); k < n; k += 64) dst[k] = src[k];
+    }
+    for (int pos = wave_id(); pos < q; pos += QW)
+        for (int i = lane_id(); i <= pos; i += 64) {
+            W.R[(size_t)pos * n + i] = (i == pos) ? S.hv[pos] : 0.0;
+            W.T[(size_t)pos * n + i] = (i == pos) ? 1.0 / S.hv[pos] : 0.0;
+        }
+    __syncthreads();
+    TOC(t_cr, 9);
     int refreshes = 0;
     for (;;) {
+        TIC(t_scan);
         rows_times(P, S.x, S.ax);
         double worst = 0.0; int p = -1;
         for (int c = threadIdx.x; c < P.m1; c += QT) {
@@ -477,10 +609,13 @@ restart:
             if (s < -tol && s < worst) { worst = s; p = c; }
         }
         block_argmin(worst, p, S);
+        TOC(t_scan, 0);
         if (p < 0) {
             if (refreshes < 1 && q > 0) {
                 double kk[3];
+                TIC(t_k0);
                 int okr = kkt_solve(P, W, S, rho, S.gr, S.act, q, S.xp, S.up, kk) == 0;
+                TOC(t_k0, 7);
                 if (okr) {
                     double mn = 0.0;
                     for (int j = threadIdx.x; j < q; j += QT) mn = fmax(mn, -S.up[j]);
@@ -503,21 +638,33 @@ restart:
         __syncthreads();
         int dropped_guard = 0;
         for (;;) {
+            TIC(t_d);
             rowdot(W.JT, n, S.np, S.d);
+            TOC(t_d, 1);
+            TIC(t_z);
             coldot(W.JT, n, q, S.d, S.z, 1.0);
+            TOC(t_z, 2);
+            TIC(t_r);
             double pz = 0.0, p1 = 0.0;
             for (int j = threadIdx.x; j < n; j += QT) { double v = S.d[j] * S.d[j]; if (j >= q) pz += v; else p1 += v; }
             double znorm2 = block_sum(pz, S), d1n = block_sum(p1, S);
-            // r = R^-1 d1 (column-oriented back substitution)
-            for (int i = threadIdx.x; i < q; i += QT) S.r[i] = S.d[i];
-            __syncthreads();
-            for (int k = q - 1; k >= 0; --k) {
-                double rk = S.r[k] / W.R[(size_t)k * n + k];
-                __syncthreads();
-                if (threadIdx.x == 0) S.r[k] = rk;
-                for (int i = threadIdx.x; i < k; i += QT) S.r[i] -= W.R[(size_t)k * n + i] * rk;
-                __syncthreads();
+            // r = R^-1 d1 = T d1 with the explicit inverse (no serial back substitution)
+            for (int i = threadIdx.x; i < q; i += QT) {
+                double acc = 0.0;
+                int k = i;
+                for (; k + 8 <= q; k += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = W.T[(size_t)(k + u) * n + i];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u] * S.d[k + u];
+                }
+                for (; k < q; ++k) acc += W.T[(size_t)k * n + i] * S.d[k];
+                S.r[i] = acc;
             }
+            __syncthreads();
+            TOC(t_r, 3);
+            TIC(t_s);
             int z_zero = (znorm2 <= 1e-26 * (1.0 + d1n + znorm2));
             double t1 = INFINITY; int l = -1;
             for (int j = threadIdx.x; j < q; j += QT)
@@ -531,12 +678,15 @@ restart:
             double t2 = z_zero ? INFINITY : -sp / znorm2;
             if (t2 < 0.0) t2 = 0.0;
             double t = t1 < t2 ? t1 : t2;
+            TOC(t_s, 4);
             if (!isfinite(t)) { status = 1; goto done; }
             if (z_zero || t2 == INFINITY) {
                 __syncthreads();
                 for (int j = threadIdx.x; j < q; j += QT) S.u[j] -= t * S.r[j];
                 if (threadIdx.x == 0) { S.u[q] += t; S.is_act[S.act[l]] = 0; }
+                TIC(t_dr0);
                 gi_drop(W, S, n, q, l);
+                TOC(t_dr0, 6);
                 --q;
                 if (++dropped_guard > 4 * n + 16) { status = 2; goto done; }
                 continue;
@@ -547,15 +697,19 @@ restart:
             if (threadIdx.x == 0) S.u[q] += t;
             __syncthreads();
             if (t == t2) {
+                TIC(t_add);
                 if (gi_add(W, S, n, q) == 0) {
                     if (threadIdx.x == 0) { S.act[q] = p; S.is_act[p] = 1; }
                     ++q;
                 }
                 __syncthreads();
+                TOC(t_add, 5);
                 break;
             }
             if (threadIdx.x == 0) S.is_act[S.act[l]] = 0;
+            TIC(t_dr1);
             gi_drop(W, S, n, q, l);
+            TOC(t_dr1, 6);
             --q;
             if (++dropped_guard > 4 * n + 16) { status = 2; goto done; }
         }
@@ -589,10 +743,16 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
     {
         double* w = a.ws + (size_t)blockIdx.x * a.ws_stride;
         const size_t nn = (size_t)n * n;
-        W.Hs = w; W.J0T = w + nn; W.JT = w + 2 * nn; W.R = w + 3 * nn; W.K = w + 4 * nn;
+        W.Hs = w; W.J0T = w + nn; W.JT = w + 2 * nn; W.R = w + 3 * nn; W.R2 = w + 4 * nn; W.T = w + 5 * nn; W.T2 = w + 6 * nn; W.K = w + 7 * nn;
     }
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // problems are handed out through a counter: solve times differ by an order of magnitude
+    // (proximal rounds of degenerate problems), a static split would leave most workgroups idle
+    for (;;) {
         __syncthreads();
+        if (threadIdx.x == 0) S.ired[6] = atomicAdd(a.counter, 1);
+        __syncthreads();
+        const int b = S.ired[6];
+        if (b >= a.B) break;
         Prob P;
         P.n = n; P.nC = nC; P.m1 = 2 * (nC + n);
         P.H = a.H + (size_t)b * n * n;
@@ -615,6 +775,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
         const int max_prox = a.max_prox > 0 ? a.max_prox : 8;
         double* L = W.K;
         int chol_ok = 0;
+        TIC(t_ch);
         for (int tries = 0; tries < 60; ++tries) {
             for (int idx = threadIdx.x; idx < n * n; idx += QT) {
                 int i = idx / n, j = idx % n;
@@ -628,6 +789,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
         int status = 1, tot_iters = 0, q = 0;
         if (chol_ok) {
             tri_inverse(L, W.J0T, n);
+            TOC(t_ch, 8);
             // crash list: lower bounds of curvature-free variables with positive cost
             // S.hv[j] = 1 if variable j has any curvature
             for (int j = threadIdx.x; j < n; j += QT) {
@@ -671,11 +833,16 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
                 for (int i = threadIdx.x; i < n; i += QT) S.gr[i] = P.g[i] - rho * S.xc[i];
                 __syncthreads();
                 int iters = 0;
+                TIC(t_gi);
                 int rc = gi_solve(P, W, S, rho, n_crash, q, iters, 20 * (n + P.m1) + 100);
+                TOC(t_gi, 10);
+                if (blockIdx.x == 0 && threadIdx.x == 0) { TOC(t_gi, 15); }
                 tot_iters += iters;
                 if (rc != 0) { status = 1; break; }
                 double kkt[3];
+                TIC(t_k1);
                 int prc = kkt_solve(P, W, S, 0.0, P.g, S.act, q, S.xp, S.up, kkt);
+                TOC(t_k1, 7);
                 if (prc == 0 && kkt[0] < 1e-9 && kkt[1] < 1e-9 && kkt[2] < 1e-9) {
                     for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
                     __syncthreads();
@@ -717,7 +884,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
 
 size_t eepacc_qp_dense_ws_doubles(int nV) {
     const size_t n = (size_t)nV;
-    return 4 * n * n + (2 * n + 2) * (2 * n + 2);
+    return 7 * n * n + (2 * n + 2) * (2 * n + 2);
 }
 
 size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
@@ -727,6 +894,15 @@ size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
     size_t bytes = dbl * 8 + ints * 4 + 2 * ((size_t)nC + n) + 16;
     return (bytes + 15) & ~(size_t)15;
 }
+
+#ifdef EEPACC_QP_TIMING
+extern "C" int eepacc_debug_qp_prof(long long* out, int reset) {
+    long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qp_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 hipError_t eepacc_qp_dense_launch(const eepacc_qp_args& a, int grid, hipStream_t stream) {
     size_t lds = eepacc_qp_dense_lds_bytes(a.nV, a.nC);
