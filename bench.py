@@ -23,28 +23,45 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def cpu_baseline(OPT, V, sc, n_inst=2, n_steps=60):
-    """The oracle (literal dense condensing + dense active set) on the host, one thread, on a
-    bounded sample of the same workload."""
+def cpu_baseline(OPT, V, sc, kind="ab", n_inst=2, n_steps=60):
+    """The oracle (literal dense condensing + dense active set) on the host on a bounded sample of
+    the same workload: (i) one thread, (ii) one instance per thread on every host core
+    (the C oracle is re-entrant and ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import Oracle
     orc = Oracle(OPT, V)
+
+    def one(i):
+        orc.run(kind, n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:n_steps, i].copy(), sc["v_tv"][:n_steps, i].copy())
+        return n_steps
+
     t0 = time.perf_counter()
-    done = 0
-    for i in range(n_inst):
-        traj, st, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:n_steps, i].copy(),
-                              sc["v_tv"][:n_steps, i].copy())
-        done += n_steps
+    done = sum(one(i) for i in range(n_inst))
     dt = time.perf_counter() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))        # a one-GPU box offers 16 host cores to the job
+    n_all = min(2 * cores, sc["v0"].shape[0])
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        done_all = sum(ex.map(one, range(n_all)))
+    dt_all = time.perf_counter() - t1
     return dict(value=done / dt, unit="QP steps/s", cores=1, kind="port",
-                sample="%d S2 instances x %d closed-loop steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
-                       % (n_inst, n_steps, OPT["N_hor"]))
+                sample="%d S2 instances x %d closed-loop %sMPC steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
+                       % (n_inst, n_steps, kind.upper(), OPT["N_hor"]),
+                all_cores={"value": done_all / dt_all, "cores": cores,
+                           "sample": "%d instances x %d steps, one instance per thread" % (n_all, n_steps)})
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["abmpc", "fbmpc"], default="abmpc",
+                    help="abmpc: the headline (BASELINE.json configs[1]); fbmpc: configs[2], same contract")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
@@ -65,7 +82,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank
-    N, B, K, W = args.horizon, args.batch, args.steps, args.warmup
+    fb = args.workload == "fbmpc"
+    K = args.steps if args.steps is not None else (6 if fb else 200)
+    W = args.warmup if args.warmup is not None else (2 if fb else 20)
+    N, B = args.horizon, args.batch
     OPT, V, _, _ = make_case("ABO", N)
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
     lo, _ = shard_range(rank, world, B)                                  # rank r owns instances [rB, (r+1)B)
@@ -81,7 +101,8 @@ def main():
            torch.empty((max(chunk, W), B), dtype=torch.int32, device=d))
 
     def run(lo, hi, resume):
-        return eng.run_abmpc(s0, v0, am1, s_tv[lo:hi], v_tv[lo:hi], resume=resume, out=buf)
+        f = eng.run_fbmpc if fb else eng.run_abmpc
+        return f(s0, v0, am1, s_tv[lo:hi], v_tv[lo:hi], resume=resume, out=buf)
 
     def kpis(traj, bad):
         # the quantities Main.m:203-263 prints, reduced over this rank's instances
@@ -125,7 +146,7 @@ def main():
     if rank == 0:
         total_steps = world * B * K
         value = total_steps / dt
-        nV, nC = 5 * N, 14 * N + 2
+        nV, nC = (6 * N, 26 * N + 2) if fb else (5 * N, 14 * N + 2)
         bytes_mat = 8 * (nV * nV + nC * nV + 3 * nV + 2 * nC) + 8 * (nV + 1)     # SURVEY 8d, R-materialised
         bytes_fused = 152                                                          # SURVEY 8d, R-fused (compulsory)
         launch_s = (kernel_ms / 1e3) / launches
@@ -138,27 +159,40 @@ def main():
             traffic = per_qp * qp_per_launch
         except Exception:
             pass
+        kname = "k_qp_dense (+ k_fb_build, k_fb_apply)" if fb else "k_run_abmpc"
+        if fb:
+            traffic = None
+            try:   # raw FETCH_SIZE + WRITE_SIZE (KB) of one k_qp_dense launch at this size; 8-byte-per-lane accesses, uncalibrated
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_fb_summary.json")))
+                traffic = (prof["pmc"]["FETCH_SIZE"] + prof["pmc"]["WRITE_SIZE"]) * 1024.0
+            except Exception:
+                pass
+            launches = K                    # one build + QP + extraction launch group per MPC step
+            launch_s = (kernel_ms / 1e3) / launches
+            qp_per_launch = B
+            achieved_mat = bytes_mat * qp_per_launch / launch_s / 1e9
         res = {
-            "metric": "QP steps/sec (whole node), ABMPC N=30 dense QP at batch 4096",
+            "metric": "QP steps/sec (whole node), %s N=%d dense QP at batch %d" % ("FBMPC" if fb else "ABMPC", N, B),
             "value": value, "unit": "QP steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ABMPC N=%d fp64, batch=%d synthetic S2 ego/lead scenarios per GPU, closed loop" % (N, B),
+            "config": {"workload": "%s N=%d fp64, batch=%d synthetic S2 ego/lead scenarios per GPU, closed loop"
+                                   % ("FBMPC" if fb else "ABMPC", N, B),
                        "batch_per_gpu": B, "horizon": N, "steps_per_launch": int(K / launches),
                        "parallelism": "instances sharded across %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved_mat, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved_mat / 8000.0, "traffic": traffic,
                          "definition": "R-materialised (SURVEY.md 8d): bytes the reference's dense-QP API moves per QP step "
-                                       "(%d B at N=%d) x QP steps per launch / mean k_run_abmpc launch time (HIP events); "
-                                       "the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it"
-                                       % (bytes_mat, N, bytes_fused),
-                         "kernel": "k_run_abmpc", "launches": launches, "launch_ms": launch_s * 1e3},
-            "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (K / launches),
+                                       "(%d B at N=%d) x QP steps per launch / mean launch time (HIP events)%s"
+                                       % (bytes_mat, N, "; FBMPC materialises exactly this QP in HBM for the dense QP operator" if fb else
+                                          "; the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it" % bytes_fused),
+                         "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3},
+            "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (1 if fb else K / launches),
                        "bad_exits": int(kpi[0].item())},
             "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
         }
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(OPT, V, sc)
+            res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 1, 20) if fb else cpu_baseline(OPT, V, sc)
             res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(res))
     if world > 1:

@@ -250,3 +250,39 @@ def RunOpt_ABMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = No
                        ("cost_xi_s", W[4], sol["xi_s_opt"]), ("cost_xi_f", W[4], sol["xi_f_opt"])):
         sol[nm] = w * np.cumsum(arr)[:N_sim]
     return sol
+
+
+def RunOpt_FBMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = None, device: int = 0) -> Dict[str, Any]:
+    """optSol = RunOpt_FBMPC(OPTsettings)  -- ABO/RunOpt_FBMPC.m:1, single ego vehicle.
+
+    Same inputs and optSol fields (:345-397) except tLoop/tSolve and the final-step H, G."""
+    from .settings import SetVehicleParameters
+    if V is None:
+        V = SetVehicleParameters(OPTsettings.get("tree", "ABO"))
+    eng = Engine(OPTsettings, V, device=device, max_batch=1)
+    t = eng.torch
+    Ts = float(OPTsettings["Tvec"][0])
+    n_steps = int(round(OPTsettings["t_sim"] / Ts)) + 1
+    s_tv = np.asarray(OPTsettings["s_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
+    v_tv = np.asarray(OPTsettings["v_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
+    traj, status = eng.run_fbmpc([OPTsettings["s_init"]], [OPTsettings["v_init"]], [OPTsettings["a_minus1"]], s_tv, v_tv)
+    rpm, Tm, P, E = eng.postprocess(traj)
+    t.cuda.synchronize()
+    tr = traj.cpu().numpy()[:, :, 0]
+    sol: Dict[str, Any] = {}
+    for name, key in (("s", "s_opt"), ("v", "v_opt"), ("Fm", "Fm_opt"), ("Fb", "Fb_opt"), ("xi_v", "xi_v_opt"),
+                      ("xi_h", "xi_h_opt"), ("xi_s", "xi_s_opt"), ("xi_f", "xi_f_opt"), ("a", "a_opt"),
+                      ("DistHor", "DistHor"), ("cost", "cost")):
+        sol[key] = tr[:, OUT[name]].copy()
+    sol["exitMessage"] = status.cpu().numpy()[:, 0].astype(np.float64)
+    sol["rpm_opt"] = rpm.cpu().numpy()[:, 0]; sol["Tm_opt"] = Tm.cpu().numpy()[:, 0]
+    sol["P_opt"] = P.cpu().numpy()[:, 0]; sol["E_opt"] = E.cpu().numpy()[:, 0]
+    sol["j_opt"] = np.diff(sol["a_opt"]) / Ts
+    W = np.asarray(OPTsettings["W_FB"]).ravel()      # :373-390
+    N_sim = n_steps - 1
+    for nm, w, arr in (("cost_P", W[0], sol["P_opt"] ** 2), ("cost_a", W[1], sol["a_opt"] ** 2),
+                       ("cost_j", W[2], sol["j_opt"] ** 2), ("cost_xi_v", W[3], sol["xi_v_opt"]),
+                       ("cost_xi_h", W[4], sol["xi_h_opt"]), ("cost_xi_s", W[5], sol["xi_s_opt"]),
+                       ("cost_xi_f", W[6], sol["xi_f_opt"])):
+        sol[nm] = w * np.cumsum(arr)[:N_sim]
+    return sol

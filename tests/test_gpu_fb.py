@@ -218,3 +218,30 @@ def test_fb_batch_properties(torch_mod, lead_trace):
         for k in range(n_steps - 1):
             s1, v1 = orc.plant(tr[k, OUT["s"], i], tr[k, OUT["v"], i], tr[k, OUT["Fm"], i], tr[k, OUT["Fb"], i])
             assert abs(s1 - tr[k + 1, OUT["s"], i]) < 1e-9 and abs(v1 - tr[k + 1, OUT["v"], i]) < 1e-10
+
+
+def test_runopt_mirrors_return_the_reference_struct(torch_mod):
+    """optSol = RunOpt_ABMPC(OPTsettings) / RunOpt_FBMPC(OPTsettings): field names and values of the
+    saved solutions (ABO/RunOpt_ABMPC.m:354-404, ABO/RunOpt_FBMPC.m:345-397)."""
+    from eepacc_mpc_casadi_matlab_amd.engine import RunOpt_ABMPC, RunOpt_FBMPC
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    OPT = dict(OPT); OPT["s_tv"] = s_tv; OPT["v_tv"] = v_tv
+    G = load_golden("abo_abmpc")
+    sol = RunOpt_ABMPC(OPT, V)
+    for key in ("s_opt", "v_opt", "Fm_opt", "Fb_opt", "a_opt", "xi_v_opt", "xi_h_opt", "P_opt", "E_opt", "Tm_opt",
+                "rpm_opt", "j_opt", "DistHor", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h"):
+        ref = np.asarray(G[key], dtype=np.float64).ravel()
+        assert sol[key].shape == ref.shape, key
+        assert np.abs(sol[key] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), key
+    assert sol["exitMessage"].sum() == 0
+    OPT, V, s_tv, v_tv = make_case("ORIG", 20)
+    OPT = dict(OPT); OPT["s_tv"] = s_tv; OPT["v_tv"] = v_tv; OPT["t_sim"] = 60.0
+    G = load_golden("orig_fbmpc")
+    sol = RunOpt_FBMPC(OPT, V)
+    n = 121
+    for key in ("s_opt", "v_opt", "xi_v_opt", "xi_h_opt", "rpm_opt", "DistHor"):
+        assert np.abs(sol[key] - np.asarray(G[key]).ravel()[:n]).max() < 1e-8, key
+    for key in ("Fm_opt", "Tm_opt", "P_opt"):                   # k = 0: degenerate force split (SURVEY 8c)
+        ref = np.asarray(G[key]).ravel()[1:n]
+        assert np.abs(sol[key][1:] - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), key
+    assert set(("cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f")) <= set(sol)

@@ -5,11 +5,12 @@ import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+PMC_KERNEL = os.environ.get("PMC_KERNEL", "k_run_abmpc")   # kernel whose counters are kept (last dispatch)
 out = {"tag": tag, "kernels": [], "pmc": {}}
 f = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    keep = [r for r in rows if "eepacc" in r["Name"]]
+    keep = [r for r in rows if "eepacc" in r["Name"] or "k_qp_dense" in r["Name"] or "k_fb_" in r["Name"]]
     with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows[:12])
     for r in keep:
@@ -19,14 +20,14 @@ if f:
     out["dispatches"] = [dict(kernel=r["Kernel_Name"][:60], dur_ms=(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
                               vgpr=r.get("VGPR_Count"), agpr=r.get("Accum_VGPR_Count"), sgpr=r.get("SGPR_Count"),
                               lds=r.get("LDS_Block_Size"), scratch=r.get("Scratch_Size"), grid=r.get("Grid_Size"), wg=r.get("Workgroup_Size"))
-                         for r in csv.DictReader(open(f[0])) if "eepacc" in r["Kernel_Name"]]
+                         for r in csv.DictReader(open(f[0])) if "eepacc" in r["Kernel_Name"]][-12:]
 for d in pmc_dirs:
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not f:
         continue
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f[0])):
-        if "k_run_abmpc" in r["Kernel_Name"]:
+        if PMC_KERNEL in r["Kernel_Name"]:
             agg[(int(r["Dispatch_Id"]), r["Counter_Name"])] += float(r["Counter_Value"])
     last = max(k[0] for k in agg) if agg else None
     for (disp, name), v in agg.items():
