@@ -849,6 +849,24 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
                     status = 0;
                     break;
                 }
+                // Degenerate optimal face (singular KKT matrix, e.g. the FB force split): the proximal
+                // rounds only creep along it.  Jump to their limit: KKT solve on the working set with a
+                // vanishing proximal term centred at the current point, verified like the exact polish.
+                {
+                    const double rho2 = 1e-9 * hmax;
+                    for (int i = threadIdx.x; i < n; i += QT) S.gr[i] = P.g[i] - rho2 * S.x[i];
+                    __syncthreads();
+                    double kk2[3];
+                    TIC(t_k2);
+                    int prc2 = kkt_solve(P, W, S, rho2, S.gr, S.act, q, S.xp, S.up, kk2);
+                    TOC(t_k2, 7);
+                    if (prc2 == 0 && kk2[0] < 1e-9 && kk2[1] < 1e-9 && kk2[2] < 1e-9) {
+                        for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
+                        __syncthreads();
+                        status = 0;
+                        break;
+                    }
+                }
                 double pdx = 0.0, pnx = 0.0;
                 for (int i = threadIdx.x; i < n; i += QT) {
                     double dd = S.x[i] - S.xc[i];

@@ -577,10 +577,39 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
             status = 0; polished = 1;
             break;
         }
+        /* Degenerate optimal face (singular KKT matrix, e.g. the FB force split): the
+         * proximal rounds then only creep along that face.  Jump to their limit: KKT solve on the
+         * working set with a vanishing proximal term centred at the current point, verified like the
+         * exact polish (a wrong working set fails the verification and the rounds go on). */
+        {
+            const int same = 1;
+            if (same) {
+                const double rho2 = 1e-9 * hmax;
+                double* Hr = (double*)malloc(sizeof(double) * (size_t)nV * nV);
+                double* gr2 = (double*)malloc(sizeof(double) * nV);
+                for (int i = 0; i < nV; ++i) {
+                    for (int j = 0; j < nV; ++j)
+                        Hr[IDX(i, j, nV)] = 0.5 * (H[IDX(i, j, nV)] + H[IDX(j, i, nV)]) + (i == j ? rho2 : 0.0);
+                    gr2[i] = g[i] - rho2 * x[i];
+                }
+                double kk2[3];
+                int prc2 = kkt_polish(nV, Hr, gr2, A, &C, act, q, xp, up, kk2);
+                free(Hr); free(gr2);
+                if (getenv("ORC_DEBUG")) fprintf(stderr, "   face solve rc=%d kkt=%g %g %g\n", prc2, kk2[0], kk2[1], kk2[2]);
+                if (prc2 == 0 && kk2[0] < 1e-9 && kk2[1] < 1e-9 && kk2[2] < 1e-9) {
+                    memcpy(x, xp, sizeof(double) * nV);
+                    memcpy(u, up, sizeof(double) * q);
+                    kkt[0] = kk2[0]; kkt[1] = kk2[1]; kkt[2] = kk2[2];
+                    status = 0; polished = 2;
+                    break;
+                }
+            }
+        }
         /* converged proximal sequence without a clean polish (degenerate vertex): accept */
         double dx = 0.0, nx = 0.0;
         for (int i = 0; i < nV; ++i) { dx += (x[i] - xc[i]) * (x[i] - xc[i]); nx += x[i] * x[i]; }
         memcpy(xc, x, sizeof(double) * nV);
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "   prox step |dx| = %g, |x| = %g, rho = %g\n", sqrt(dx), sqrt(nx), rho);
         if (it > 0 && sqrt(dx) <= 1e-13 * (1.0 + sqrt(nx))) { status = 0; break; }
     }
     if (cost) {

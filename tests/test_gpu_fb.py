@@ -240,7 +240,8 @@ def test_runopt_mirrors_return_the_reference_struct(torch_mod):
     sol = RunOpt_FBMPC(OPT, V)
     n = 121
     for key in ("s_opt", "v_opt", "xi_v_opt", "xi_h_opt", "rpm_opt", "DistHor"):
-        assert np.abs(sol[key] - np.asarray(G[key]).ravel()[:n]).max() < 1e-8, key
+        ref = np.asarray(G[key]).ravel()[:n]
+        assert np.abs(sol[key] - ref).max() <= 1e-9 * max(10.0, np.abs(ref).max()), key
     for key in ("Fm_opt", "Tm_opt", "P_opt"):                   # k = 0: degenerate force split
         ref = np.asarray(G[key]).ravel()[1:n]
         assert np.abs(sol[key][1:] - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), key

@@ -150,13 +150,14 @@ def test_fb_final_step_dense_H_G(tree):
 def test_fb_closed_loop_871_steps(tree):
     """Oracle FBMPC closed loop against the saved FB solution.  k = 0 is the degenerate force split
     of SURVEY.md section 8c (only Fm+Fb is determined), so Fm/Fb are compared as their sum; the ABO
-    golden has two more such steps, which bounds its tolerances."""
+    golden has two more steps (251, 691) on which the proximal rounds do not settle within their
+    cap (status 1), which bounds its tolerances."""
     OPT, V, s_tv, v_tv = make_case(tree, 20)
     G = load_golden(f"{tree.lower()}_fbmpc")
     orc = Oracle(OPT, V)
     ref, st, it = orc.run("fb", 871, 0.0, 0.0, 0.0, s_tv, v_tv)
     tol = 2e-6 if tree == "ABO" else 1e-9
-    assert st.sum() <= 3 and st[0] == 1
+    assert st.sum() <= 2 and st[0] == 0        # k = 0 is resolved by the degenerate-face solve
     for n, g in (("s", "s_opt"), ("v", "v_opt"), ("xi_v", "xi_v_opt"), ("xi_h", "xi_h_opt"), ("xi_s", "xi_s_opt"),
                  ("xi_f", "xi_f_opt")):
         assert np.abs(ref[:, OUT[n]] - G[g]).max() < tol, n
