@@ -40,6 +40,7 @@ struct eepacc_handle {
     DevCfg cfg;
     DevCfg* d_cfg = nullptr;
     double* d_Hinv = nullptr;
+    double* d_pred = nullptr;                // [max_batch][2][64] previous predictions (paramEstSetting 2)
     unsigned long long* d_codes = nullptr;   // [max_batch][64]
     int32_t* d_iters = nullptr;              // [max_batch]
     double* d_carry = nullptr;               // [6][B] closed-loop carry (see k_run_abmpc)
@@ -91,7 +92,7 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     if (N < 2 || N > eepacc::kMaxN) return fail(EEPACC_EINVAL, "N_hor must be in [2, 63]");
     if (!S->Tvec) return fail(EEPACC_EINVAL, "Tvec is NULL");
     if (S->solverToUse != 1) return fail(EEPACC_ENOTSUP, "only solverToUse == 1 (dense QP, ABO/Settings.m:114) is built");
-    if (S->paramEstSetting != 0 && S->paramEstSetting != 1) return fail(EEPACC_ENOTSUP, "paramEstSetting 2 is not built yet");
+    if (S->paramEstSetting < 0 || S->paramEstSetting > 2) return fail(EEPACC_EINVAL, "paramEstSetting must be 0, 1 or 2");
     if (S->TVestSetting != 0 && S->TVestSetting != 1) return fail(EEPACC_EINVAL, "TVestSetting must be 0 or 1");
     if (S->n_speedLim < 1 || S->n_speedLim > eepacc::kMaxKnots || S->n_curv < 1 || S->n_curv > eepacc::kMaxKnots ||
         S->n_slope < 1 || S->n_slope > eepacc::kMaxKnots || S->n_stop < 0 || S->n_stop > eepacc::kMaxStops ||
@@ -194,6 +195,9 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMalloc(&h->d_Hinv, Hinv.size() * sizeof(double)));
     HIPCHK(hipMemcpy(h->d_Hinv, Hinv.data(), Hinv.size() * sizeof(double), hipMemcpyHostToDevice));
     C.Hinv = h->d_Hinv;
+    HIPCHK(hipMalloc(&h->d_pred, (size_t)max_batch * 128 * sizeof(double)));
+    HIPCHK(hipMemset(h->d_pred, 0, (size_t)max_batch * 128 * sizeof(double)));
+    C.pred = h->d_pred;
     h->cfg = C;
     HIPCHK(hipMalloc(&h->d_cfg, sizeof(DevCfg)));
     HIPCHK(hipMemcpy(h->d_cfg, &C, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -230,6 +234,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     if (h->d_Hinv) (void)hipFree(h->d_Hinv);
+    if (h->d_pred) (void)hipFree(h->d_pred);
     if (h->d_codes) (void)hipFree(h->d_codes);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_carry) (void)hipFree(h->d_carry);
@@ -245,6 +250,7 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     if (!h) return fail(EEPACC_EINVAL, "NULL handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemset(h->d_codes, 0, (size_t)h->max_batch * 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_pred, 0, (size_t)h->max_batch * 128 * sizeof(double)));
     h->k_done = 0; h->carry_B = 0;
     h->fb_k_done = 0;
     if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));

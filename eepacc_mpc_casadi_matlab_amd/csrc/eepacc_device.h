@@ -59,6 +59,7 @@ struct DevCfg {
     double b_quadr[6];
     int32_t FBuseTaylor, fb_pad;
     const double* Hinv;           // device, [N][N] row-major, inverse of the a-space Hessian
+    double* pred;                 // device, [max_batch][2][64]: previous predicted s, v (paramEstSetting 2)
 };
 
 }  // namespace eepacc

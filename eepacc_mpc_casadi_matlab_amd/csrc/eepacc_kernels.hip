@@ -950,7 +950,8 @@ struct StepOut { double out[EEPACC_OUT_N]; int status, iters; };
 // working set between steps (already shifted by the caller).
 template <int MMAX, int NS>
 __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, double* Hs, const StepIn& in,
-                        unsigned long long& code, StepOut& so, double& s_pred, double& v_pred) {
+                        unsigned long long& code, StepOut& so, double& s_pred, double& v_pred,
+                        const double* predp, bool pred_in_lds) {
     Lane L;
     L.lane = lane_id(); L.N = C.N;
     const int lane = L.lane, N = C.N;
@@ -963,7 +964,17 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, d
     c.N = N; c.tau_min = C.tau_min; c.wF = C.w_f; c.wS = C.w_s; c.wV = C.w_v; c.wH = 100.0 * C.w_h; c.qH = 2.0 * C.w_h;
     // estimators (A2)
     double s_est, v_est, stv_est, vtv_est;
-    estimate_traj(C, C.paramEstSetting, C.tConstACC_ego, in.s, in.v, in.a_prev, lane, s_est, v_est);
+    if (C.paramEstSetting == 2) {
+        // EstimateVehicleTrajectory.m:81-88: shifted previous solution, [x_curr; prev(3:end); prev(end) + Ts v_prev(end)]
+        // (previous z(1:7:end), z(2:7:end) kept in LDS between the steps of a launch, in C.pred across launches)
+        const int idx = lane < N ? lane + 1 : N;
+        const double ps = pred_in_lds ? M.ws[idx] : predp[idx], pv = pred_in_lds ? M.wv[idx] : predp[64 + idx];
+        s_est = lane == 0 ? in.s : (lane < N ? ps : ps + C.Tvec[N - 1] * pv);
+        v_est = lane == 0 ? in.v : pv;
+        WSYNC();
+    } else {
+        estimate_traj(C, C.paramEstSetting, C.tConstACC_ego, in.s, in.v, in.a_prev, lane, s_est, v_est);
+    }
     estimate_traj(C, C.TVestSetting, C.tConstACC_tar, in.s_tv, in.v_tv, in.a_tv_prev, lane, stv_est, vtv_est);
     const double dist_hor = bcast(s_est, N) - in.s;                          // :200
     const double stv_Nm1 = bcast(stv_est, N - 1);
@@ -1120,7 +1131,9 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
     unsigned long long code = codes[(size_t)b * 64 + lane];
     StepOut so;
     double sp, vp;
-    ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp);
+    double* predp = C.pred + (size_t)b * 128;
+    ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp, predp, false);
+    if (C.paramEstSetting == 2 && lane <= C.N) { predp[lane] = sp; predp[64 + lane] = vp; }
     codes[(size_t)b * 64 + lane] = shift_codes(code, C.N);
     if (lane < EEPACC_OUT_N) {
         double val = 0.0;
@@ -1188,6 +1201,7 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
         code = codes[(size_t)b * 64 + lane];
     }
     int it_total = 0;
+    double* predp = C.pred + (size_t)b * 128;
     for (int kk = kk0; kk < kk1; ++kk) {
         StepIn in;
         if (k_start + kk == 0) {                             // :159-172
@@ -1208,7 +1222,13 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
         in.t0 = t_0;
         StepOut so;
         double sp, vp;
-        ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp);
+        ab_step<MMAX, NS>(C, M, Hs, in, code, so, sp, vp, predp, kk > kk0);
+        if (C.paramEstSetting == 2) {
+            WSYNC();
+            if (lane <= C.N) { M.ws[lane] = sp; M.wv[lane] = vp; }
+            WSYNC();
+            if (kk == kk1 - 1 && lane <= C.N) { predp[lane] = sp; predp[64 + lane] = vp; }
+        }
         code = shift_codes(code, C.N);
         if (lane < EEPACC_OUT_N) {
             double val = 0.0;

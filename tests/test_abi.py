@@ -66,7 +66,7 @@ def test_settings_validation_messages(lib):
     """eepacc_create rejects settings the kernels do not implement before touching the GPU."""
     OPT, V, *_ = make_case("ABO", 20)
     veh = make_vehicle(V)
-    for key, val, code in (("solverToUse", 2, -4), ("paramEstSetting", 2, -4)):
+    for key, val, code in (("solverToUse", 2, -4), ("paramEstSetting", 3, -1), ("TVestSetting", 2, -1)):
         o = dict(OPT); o[key] = val
         holder = SettingsHolder(o)
         h = C.c_void_p()

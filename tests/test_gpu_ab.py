@@ -196,10 +196,11 @@ def _route_case(tree, N, **kw):
 @pytest.mark.parametrize("tree", ["ABO", "ORIG"])
 def test_route_features_and_estimator_modes(tree, torch_mod, lead_trace):
     """Speed-limit steps, curves, stops, traffic lights, road slope (non-constant: the sin/cos path of
-    the plant), and the constant-velocity estimator modes -- none of these has a reference golden, the
-    oracle is the checker (closed loop, 90 steps)."""
+    the plant), and the estimator modes 0 (constant velocity) and 2 (shifted previous solution,
+    EstimateVehicleTrajectory.m:81-88) -- none of these has a reference golden, the oracle is the
+    checker (closed loop, 90 steps)."""
     from oracle import Oracle
-    for est in (dict(), dict(paramEstSetting=0, TVestSetting=0)):
+    for est in (dict(), dict(paramEstSetting=0, TVestSetting=0), dict(paramEstSetting=2)):
         OPT, V = _route_case(tree, 20, **est)
         B, n_steps = 4, 90
         sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=7)
@@ -215,6 +216,10 @@ def test_route_features_and_estimator_modes(tree, torch_mod, lead_trace):
             ok = rst == 0
             for n, t in tol.items():
                 assert np.abs(tr[ok, OUT[n], i] - ref[ok, OUT[n]]).max() < t, (tree, est, i, n)
+        if est.get("paramEstSetting") == 2:       # the previous solution also travels between launches
+            t1, _ = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"][:37], sc["v_tv"][:37])
+            t2, _ = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"][37:], sc["v_tv"][37:], resume=True)
+            np.testing.assert_array_equal(np.concatenate([t1.cpu().numpy(), t2.cpu().numpy()]), tr)
 
 
 def test_variable_time_steps(torch_mod, lead_trace):
