@@ -59,6 +59,7 @@ struct eepacc_handle {
     double *fb_H = nullptr, *fb_g = nullptr, *fb_A = nullptr, *fb_lba = nullptr, *fb_uba = nullptr;   // [fb_chunk]
     double *fb_x = nullptr, *fb_x0 = nullptr, *fb_cost = nullptr, *fb_meas = nullptr, *fb_carry = nullptr;   // [fb_B]
     double *fb_A22 = nullptr, *fb_D2 = nullptr;
+    double *fb_sp = nullptr, *fb_vp = nullptr;   // [N+1][fb_B] predictions of the last step
     int32_t* fb_qpstat = nullptr;
 };
 
@@ -222,7 +223,7 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
 
 static void fb_free(eepacc_handle* h) {
     double** ptrs[] = {&h->fb_H, &h->fb_g, &h->fb_A, &h->fb_lba, &h->fb_uba, &h->fb_x, &h->fb_x0, &h->fb_cost,
-                       &h->fb_meas, &h->fb_carry, &h->fb_A22, &h->fb_D2};
+                       &h->fb_meas, &h->fb_carry, &h->fb_A22, &h->fb_D2, &h->fb_sp, &h->fb_vp};
     for (double** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (h->fb_qpstat) (void)hipFree(h->fb_qpstat);
     h->fb_qpstat = nullptr;
@@ -254,6 +255,10 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     h->k_done = 0; h->carry_B = 0;
     h->fb_k_done = 0;
     if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));
+    if (h->fb_sp) {
+        HIPCHK(hipMemset(h->fb_sp, 0, (size_t)h->fb_B * (h->cfg.N + 1) * sizeof(double)));
+        HIPCHK(hipMemset(h->fb_vp, 0, (size_t)h->fb_B * (h->cfg.N + 1) * sizeof(double)));
+    }
     return EEPACC_OK;
 }
 
@@ -387,7 +392,6 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
 static int fb_prepare(eepacc_handle* h, int B) {
     const int N = h->cfg.N;
     const size_t nV = 6 * (size_t)N, nC = 26 * (size_t)N + 2;
-    if (h->cfg.paramEstSetting != 0 && h->cfg.paramEstSetting != 1) return fail(EEPACC_ENOTSUP, "FBMPC: paramEstSetting 2 is not built");
     if (nV > EEPACC_QP_MAX_NV || nC > EEPACC_QP_MAX_NC || eepacc_qp_dense_lds_bytes((int)nV, (int)nC) > 160 * 1024)
         return fail(EEPACC_ENOTSUP, "FBMPC: horizon too long for the dense QP operator");
     if (B <= h->fb_B) return EEPACC_OK;
@@ -411,11 +415,15 @@ static int fb_prepare(eepacc_handle* h, int B) {
               hipMalloc(&h->fb_carry, 5 * nB * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->fb_A22, nB * N * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->fb_D2, nB * N * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_sp, nB * (N + 1) * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->fb_vp, nB * (N + 1) * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->fb_qpstat, nB * sizeof(int32_t)) == hipSuccess;
     if (!ok) { fb_free(h); return fail(EEPACC_ENOMEM, "FBMPC: device allocation failed"); }
     HIPCHK(hipMemset(h->fb_x0, 0, nB * nV * sizeof(double)));
     HIPCHK(hipMemset(h->fb_A22, 0, nB * N * sizeof(double)));
     HIPCHK(hipMemset(h->fb_D2, 0, nB * N * sizeof(double)));
+    HIPCHK(hipMemset(h->fb_sp, 0, nB * (N + 1) * sizeof(double)));
+    HIPCHK(hipMemset(h->fb_vp, 0, nB * (N + 1) * sizeof(double)));
     h->fb_B = B; h->fb_chunk = (int)chunk;
     h->fb_k_done = 0;
     return EEPACC_OK;
@@ -432,6 +440,7 @@ static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const
         a.cfg = h->d_cfg; a.B = B; a.k_step = h->fb_k_done; a.b0 = b0; a.nb = nb; a.mode = mode;
         a.s = s; a.v = v; a.a_prev = a_prev; a.t0 = t0; a.s_tv = s_tv; a.v_tv = v_tv; a.a_tv_prev = a_tv_prev;
         a.carry = h->fb_carry; a.A22 = h->fb_A22; a.D2 = h->fb_D2;
+        a.sp_prev = h->fb_sp; a.vp_prev = h->fb_vp;
         a.H = h->fb_H; a.g = h->fb_g; a.A = h->fb_A; a.lba = h->fb_lba; a.uba = h->fb_uba; a.meas = h->fb_meas;
         HIPCHK(eepacc::launch_fb_build(a, N, stream));
         int grid = qp_grid(h, nb);
@@ -451,7 +460,13 @@ static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const
     p.cfg = h->d_cfg; p.B = B; p.x = h->fb_x; p.cost = h->fb_cost; p.qp_status = h->fb_qpstat; p.meas = h->fb_meas;
     p.A22 = h->fb_A22; p.D2 = h->fb_D2; p.out = out; p.s_pred = s_pred; p.v_pred = v_pred; p.status = status;
     p.carry = mode == 1 ? h->fb_carry : nullptr;
+    const bool keep_pred = h->cfg.paramEstSetting == 2;
+    if (keep_pred) { p.s_pred = h->fb_sp; p.v_pred = h->fb_vp; }      // stride B: fb_sp/fb_vp hold [N+1][B]
     HIPCHK(eepacc::launch_fb_apply(p, stream));
+    if (keep_pred && s_pred && v_pred) {
+        HIPCHK(hipMemcpyAsync(s_pred, h->fb_sp, (size_t)B * (N + 1) * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(v_pred, h->fb_vp, (size_t)B * (N + 1) * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
     // the solution is the proximal centre / initial guess of the next step
     HIPCHK(hipMemcpyAsync(h->fb_x0, h->fb_x, (size_t)B * nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
     h->fb_k_done += 1;

@@ -19,6 +19,7 @@ struct eepacc_fb_args {
     const double *s, *v, *a_prev, *t0, *s_tv, *v_tv, *a_tv_prev;
     const double* carry;        // [5][B]: s, v, Fm, Fb, lead speed of the previous step
     double *A22, *D2;           // [N][B] carried state-space entries (A(k)/D(k) index quirk)
+    const double *sp_prev, *vp_prev;   // [N+1][B] predictions of the previous step (paramEstSetting 2)
     double *H, *g, *A, *lba, *uba;   // dense QP, instance-major (A column-major nC x nV)
     double* meas;               // [5][B]: s, v, DistHor, lead speed, a_opt(k)
 };

@@ -155,7 +155,15 @@ __global__ void __launch_bounds__(FT) k_fb_build(eepacc_fb_args a) {
     // ---- estimators and bounds (A2, A3)
     if (tid <= N) {
         double se, ve, st, vt;
-        estimate_traj(C, C.paramEstSetting, C.tConstACC_ego, s_0, v_0, a_minus1, tid, se, ve);
+        if (C.paramEstSetting == 2) {
+            // EstimateVehicleTrajectory.m:81-88: [x_curr; prev(3:end); prev(end) + Ts v_prev(end)]
+            const int idx = tid < N ? tid + 1 : N;
+            const double ps = a.sp_prev[(size_t)idx * B + b], pv = a.vp_prev[(size_t)idx * B + b];
+            se = tid == 0 ? s_0 : (tid < N ? ps : ps + C.Tvec[N - 1] * pv);
+            ve = tid == 0 ? v_0 : pv;
+        } else {
+            estimate_traj(C, C.paramEstSetting, C.tConstACC_ego, s_0, v_0, a_minus1, tid, se, ve);
+        }
         estimate_traj(C, C.TVestSetting, C.tConstACC_tar, S.scal[4], S.scal[5], S.scal[6], tid, st, vt);
         S.s_est[tid] = se; S.v_est[tid] = ve; S.stv_est[tid] = st;
         if (tid < N)

@@ -43,6 +43,7 @@ struct Prob {            // one instance
 struct Lds {
     double *x, *xc, *gr, *np, *d, *z, *r, *u, *xp, *up, *t, *hv, *rhs, *sol, *res, *fcol, *ax, *red;
     int *act, *crash, *piv, *ired;
+    int* jend;              // per row of A: one past its last non-zero column
     unsigned char* is_act;
 };
 
@@ -138,21 +139,24 @@ __device__ double con_value(const Prob& P, int c, const double* x, const Lds& S)
     return sgn * s - b;
 }
 
-// ax = A x  (thread per row; loads issued eight at a time, summation order j = 0..n-1)
-__device__ void rows_times(const Prob& P, const double* x, double* ax) {
+// ax = A x  (thread per row; loads issued eight at a time, summation order j = 0..).  jend[i] is one
+// past the last non-zero of row i (condensed MPC rows only reach back over earlier stages): the
+// columns beyond it hold exact zeros and are not read.
+__device__ void rows_times(const Prob& P, const double* x, double* ax, const int* jend) {
     const size_t ld = (size_t)P.nC;
     for (int i = threadIdx.x; i < P.nC; i += QT) {
         double s = 0.0;
         const double* a = P.A + i;
+        const int je = jend[i];
         int j = 0;
-        for (; j + 8 <= P.n; j += 8) {
+        for (; j + 8 <= je; j += 8) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = a[(size_t)(j + u) * ld];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u] * x[j + u];
         }
-        for (; j < P.n; ++j) s += a[(size_t)j * ld] * x[j];
+        for (; j < je; ++j) s += a[(size_t)j * ld] * x[j];
         ax[i] = s;
     }
     __syncthreads();
@@ -391,7 +395,7 @@ __device__ int kkt_solve(const Prob& P, const Ws& W, const Lds& S, double rho, c
     double stat = 0.0, scale = 1.0, dneg = 0.0, pviol = 0.0;
     for (int i = threadIdx.x; i < n; i += QT) { stat = fmax(stat, fabs(S.t[i])); scale = fmax(scale, fabs(gv[i])); }
     for (int c = threadIdx.x; c < q; c += QT) { dneg = fmax(dneg, -uo[c]); scale = fmax(scale, fabs(uo[c])); }
-    rows_times(P, xo, S.ax);
+    rows_times(P, xo, S.ax, S.jend);
     for (int c = threadIdx.x; c < P.m1; c += QT) {
         int row; double sgn, b;
         if (!os_get(P, c, row, sgn, b)) continue;
@@ -599,7 +603,7 @@ __device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho,
     int refreshes = 0;
     for (;;) {
         TIC(t_scan);
-        rows_times(P, S.x, S.ax);
+        rows_times(P, S.x, S.ax, S.jend);
         double worst = 0.0; int p = -1;
         for (int c = threadIdx.x; c < P.m1; c += QT) {
             int row; double sgn, b;
@@ -731,6 +735,7 @@ __device__ void carve(Lds& S, unsigned char* base, int n, int nC) {
     S.ax = p; p += nC; S.red = p; p += 8;
     int* ip = (int*)p;
     S.act = ip; ip += n + 2; S.crash = ip; ip += 2 * n; S.piv = ip; ip += n2; S.ired = ip; ip += 8;
+    S.jend = ip; ip += nC;
     S.is_act = (unsigned char*)ip;
 }
 
@@ -802,6 +807,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
                 int nnz = 0, var = -1;
                 for (int j = 0; j < n; ++j) if (P.A[(size_t)j * nC + i] != 0.0) { ++nnz; var = j; }
                 S.ax[i] = nnz == 1 ? (double)var : -1.0;
+                S.jend[i] = var + 1;
             }
             __syncthreads();
             int n_crash = 0;
@@ -908,7 +914,7 @@ size_t eepacc_qp_dense_ws_doubles(int nV) {
 size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
     const size_t n = (size_t)nV, n2 = 2 * n + 2;
     size_t dbl = 12 * n + 4 + 4 * n2 + (size_t)nC + 8;
-    size_t ints = (n + 2) + 2 * n + n2 + 8;
+    size_t ints = (n + 2) + 2 * n + n2 + 8 + (size_t)nC;
     size_t bytes = dbl * 8 + ints * 4 + 2 * ((size_t)nC + n) + 16;
     return (bytes + 15) & ~(size_t)15;
 }

@@ -36,10 +36,11 @@ def _compare_fb(tr, ref, rst, scale=1.0):
         assert np.abs(tr[:, OUT[n]] - ref[:, OUT[n]]).max() < scale * TOL[n], n
     F = tr[:, OUT["Fm"]] + tr[:, OUT["Fb"]]
     Fr = ref[:, OUT["Fm"]] + ref[:, OUT["Fb"]]
-    assert np.abs(F - Fr).max() < scale * 1e-6
+    assert np.abs(F - Fr).max() < scale * 1e-6 + 1e-8 * np.abs(Fr).max()      # forces reach 1e4 N in hard braking
     ok = rst == 0
-    assert np.abs(tr[ok, OUT["Fm"]] - ref[ok, OUT["Fm"]]).max() < scale * 1e-6
-    assert np.abs(tr[ok, OUT["Fb"]] - ref[ok, OUT["Fb"]]).max() < scale * 1e-6
+    ftol = scale * 1e-6 + 1e-8 * np.abs(Fr).max()
+    assert np.abs(tr[ok, OUT["Fm"]] - ref[ok, OUT["Fm"]]).max() < ftol
+    assert np.abs(tr[ok, OUT["Fb"]] - ref[ok, OUT["Fb"]]).max() < ftol
     assert np.abs(tr[ok, OUT["cost"]] - ref[ok, OUT["cost"]]).max() < 1e-9 * np.abs(ref[:, OUT["cost"]]).max()
 
 
@@ -246,3 +247,22 @@ def test_runopt_mirrors_return_the_reference_struct(torch_mod):
         ref = np.asarray(G[key]).ravel()[1:n]
         assert np.abs(sol[key][1:] - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), key
     assert set(("cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f")) <= set(sol)
+
+
+def test_fb_estimator_modes(torch_mod, lead_trace):
+    """FBMPC with the constant-velocity estimators (0) and the shifted previous solution (2,
+    EstimateVehicleTrajectory.m:81-88) against the oracle closed loop."""
+    from oracle import Oracle
+    for est in (dict(paramEstSetting=0, TVestSetting=0), dict(paramEstSetting=2)):
+        OPT, V, _, _ = make_case("ABO", 20, **est)
+        B, n_steps = 3, 30
+        sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=5)
+        sc["s_tv"] = sc["s_tv"] + np.array([0.0, 40.0, 500.0])[None, :]
+        eng = _engine(OPT, V, 4)
+        traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+        tr = traj.cpu().numpy(); st = status.cpu().numpy()
+        orc = Oracle(OPT, V)
+        for i in range(B):
+            ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+            np.testing.assert_array_equal(st[:, i], rst)
+            _compare_fb(tr[:, :, i], ref, rst, scale=10.0)
