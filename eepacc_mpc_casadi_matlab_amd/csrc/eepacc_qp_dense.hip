@@ -616,9 +616,32 @@ __device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho,
         TOC(t_scan, 0);
         if (p < 0) {
             if (refreshes < 1 && q > 0) {
-                double kk[3];
+                // refresh (x,u) from the working set -- guards against drift accumulated over many
+                // rank-one steps.  The regularised KKT system is solved through the factors at hand:
+                // with J'N' = [R;0] and G^-1 = JJ':  y = R^-T b,  x = J1 y - J2 (J'gr)_2,
+                // u = R^-1 (y + (J'gr)_1)   (the oracle solves the same system by LU)
                 TIC(t_k0);
-                int okr = kkt_solve(P, W, S, rho, S.gr, S.act, q, S.xp, S.up, kk) == 0;
+                int okr = 1;
+                rowdot(W.JT, n, S.gr, S.t);                                   // t = J' gr
+                for (int k = threadIdx.x; k < q; k += QT) {                   // y = T' b
+                    int row; double sgn, b;
+                    double acc = 0.0;
+                    for (int i = 0; i <= k; ++i) {
+                        os_get(P, S.act[i], row, sgn, b);
+                        acc += W.T[(size_t)k * n + i] * b;
+                    }
+                    S.z[k] = acc;
+                }
+                __syncthreads();
+                for (int j = threadIdx.x; j < n; j += QT) S.d[j] = j < q ? S.z[j] : -S.t[j];
+                __syncthreads();
+                coldot(W.JT, n, 0, S.d, S.xp, 1.0);                           // x
+                for (int i = threadIdx.x; i < q; i += QT) {                   // u = T (y + t_1)
+                    double acc = 0.0;
+                    for (int k = i; k < q; ++k) acc += W.T[(size_t)k * n + i] * (S.z[k] + S.t[k]);
+                    S.up[i] = acc;
+                }
+                __syncthreads();
                 TOC(t_k0, 7);
                 if (okr) {
                     double mn = 0.0;
