@@ -44,6 +44,8 @@ struct Lds {
     double *x, *xc, *gr, *np, *d, *z, *r, *u, *xp, *up, *t, *hv, *rhs, *sol, *res, *fcol, *ax, *red;
     int *act, *crash, *piv, *ired;
     int* jend;              // per row of A: one past its last non-zero column
+    int* svar;              // per row of A: its column if it has exactly one non-zero, else -1
+    int *kk_kind, *kk_vmap, *kk_free, *kk_gpos;   // index maps of kkt_solve
     unsigned char* is_act;
 };
 
@@ -223,20 +225,28 @@ __device__ int chol_lower(double* L, int n, const Lds& S) {
     return 0;
 }
 
-// X = L^-1 (lower triangular, row-major), thread per column
-__device__ void tri_inverse(const double* L, double* X, int n) {
-    for (int c = threadIdx.x; c < n; c += QT) {
-        for (int i = 0; i < n; ++i) {
-            double v = 0.0;
-            if (i >= c) {
-                double s = (i == c) ? 1.0 : 0.0;
-                for (int k = c; k < i; ++k) s -= L[(size_t)i * n + k] * X[(size_t)k * n + c];
-                v = s / L[(size_t)i * n + i];
-            }
-            X[(size_t)i * n + c] = v;
-        }
-    }
+// X = L^-1 (lower triangular, row-major) by column-oriented forward substitution on the rows of X:
+// row k is final after its division; it is then eliminated from all later rows (a rank-one update
+// of the (n-k-1) x (k+1) block, rows over the wavefronts, columns over the lanes).
+__device__ void tri_inverse(const double* L, double* X, int n, const Lds& S) {
+    for (int i = wave_id(); i < n; i += QW)
+        for (int c = lane_id(); c < n; c += 64) X[(size_t)i * n + c] = (i == c) ? 1.0 : 0.0;
     __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double dk = L[(size_t)k * n + k];
+        for (int c = threadIdx.x; c <= k; c += QT) {
+            const double v = X[(size_t)k * n + c] / dk;
+            X[(size_t)k * n + c] = v;
+            S.fcol[c] = v;
+        }
+        __syncthreads();
+        for (int i = k + 1 + wave_id(); i < n; i += QW) {
+            const double lik = L[(size_t)i * n + k];
+            double* xi = X + (size_t)i * n;
+            for (int c = lane_id(); c <= k; c += 64) xi[c] -= lik * S.fcol[c];
+        }
+        __syncthreads();
+    }
 }
 
 // ---- LU with partial pivoting on K (Nk x Nk row-major, global).  returns min |pivot|
@@ -309,93 +319,140 @@ __device__ void lu_solve(const double* LU, int Nk, double* b, const Lds& S) {
     }
 }
 
-// Exact KKT solve on the working set act[0..q): [Hm N'; N 0][x; -u] = [-gv; b], Hm = Hs + rho I.
-// Outputs xo[n], uo[q]; kkt[3] (uniform).  returns 0 / -1 (singular).
-__device__ int kkt_solve(const Prob& P, const Ws& W, const Lds& S, double rho, const double* gv,
-                         const int* act, int q, double* xo, double* uo, double kkt[3]) {
-    const int n = P.n, Nk = n + q;
-    double* K = W.K;
-    __syncthreads();
-    for (int i = wave_id(); i < Nk; i += QW)
-        for (int j = lane_id(); j < Nk; j += 64) {
-            double v = 0.0;
-            if (i < n && j < n) v = W.Hs[(size_t)i * n + j] + (i == j ? rho : 0.0);
-            K[(size_t)i * Nk + j] = v;
+// residual of the full KKT system at S.sol = [x; y] (y = -u, one entry per working-set row):
+//   res[i]   = -gv[i] - (Hs + rho I) x - sum_c N[c][i] y_c      (i < n; one thread per variable)
+//   res[n+c] = b_c - n_c' x                                      (from ax = A x, left in S.ax)
+__device__ void kkt_residual(const Prob& P, const Ws& W, const Lds& S, double rho, const double* gv,
+                             const int* act, int q) {
+    const int n = P.n;
+    rows_times(P, S.sol, S.ax, S.jend);
+    for (int i = threadIdx.x; i < n; i += QT) {
+        double s = -gv[i] - rho * S.sol[i];
+        const double* h = W.Hs + (size_t)i * n;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = h[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fma(-v[u], S.sol[j + u], s);
         }
-    __syncthreads();
-    for (int c = 0; c < q; ++c) {
+        for (; j < n; ++j) s = fma(-h[j], S.sol[j], s);
+        const double* acol = P.A + (size_t)i * P.nC;
+        for (int c = 0; c < q; ++c) {
+            const int id = act[c];
+            const double sgn = (id & 1) ? -1.0 : 1.0;
+            if (id >= 2 * P.nC) {
+                if (((id - 2 * P.nC) >> 1) == i) s = fma(-sgn, S.sol[n + c], s);
+            } else {
+                const int row = id >> 1, sv = S.svar[row];
+                if (sv >= 0 ? sv == i : i < S.jend[row]) s = fma(-sgn * acol[row], S.sol[n + c], s);
+            }
+        }
+        S.res[i] = s;
+    }
+    for (int c = threadIdx.x; c < q; c += QT) {
         int row; double sgn, b;
         os_get(P, act[c], row, sgn, b);
-        for (int j = threadIdx.x; j < n; j += QT) {
-            double v = row >= 0 ? sgn * P.A[(size_t)j * P.nC + row] : (j == -row - 1 ? sgn : 0.0);
-            K[(size_t)(n + c) * Nk + j] = v;
-            K[(size_t)j * Nk + n + c] = v;
-        }
-        if (threadIdx.x == 0) S.rhs[n + c] = b;
+        S.res[n + c] = b - sgn * (row >= 0 ? S.ax[row] : S.sol[-row - 1]);
     }
-    for (int i = threadIdx.x; i < n; i += QT) S.rhs[i] = -gv[i];
     __syncthreads();
-    double minpiv = lu_factor(K, Nk, S);
-    if (minpiv < 1e-13) return -1;
-    for (int i = threadIdx.x; i < Nk; i += QT) S.sol[i] = S.rhs[i];
-    lu_solve(K, Nk, S.sol, S);
-    for (int it = 0; it < 3; ++it) {
-        // residual from the problem data (the factor overwrote K)
-        for (int i = threadIdx.x; i < n; i += QT) {
-            double s = S.rhs[i] - rho * S.sol[i];
-            for (int j = 0; j < n; ++j) s = fma(-W.Hs[(size_t)i * n + j], S.sol[j], s);
-            S.res[i] = s;
-        }
-        __syncthreads();
+}
+
+// Exact KKT solve on the working set act[0..q): [Hm N'; N 0][x; -u] = [-gv; b], Hm = Hs + rho I.
+// Working-set rows with a single non-zero (slack and variable bounds -- two thirds of a typical
+// MPC working set) fix their variable directly; LU with partial pivoting runs on the remaining
+// (free variables + general rows) system only, followed by two rounds of iterative refinement
+// against residuals evaluated from the problem data.  Outputs xo[n], uo[q]; kkt[3] (uniform).
+// returns 0 / -1 (singular).
+__device__ int kkt_solve(const Prob& P, const Ws& W, const Lds& S, double rho, const double* gv,
+                         const int* act, int q, double* xo, double* uo, double kkt[3]) {
+    const int n = P.n;
+    double* K = W.K;
+    int* kind = S.kk_kind;      // per working-set row: variable it fixes, or -1
+    int* vmap = S.kk_vmap;      // per variable: index among the free ones, or -1
+    int* freev = S.kk_free;     // free variables
+    int* gpos = S.kk_gpos;      // general working-set rows (positions in act)
+    __syncthreads();
+    for (int i = threadIdx.x; i < n + q; i += QT) S.sol[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int v = 0; v < n; ++v) vmap[v] = 0;
+        int qg = 0;
         for (int c = 0; c < q; ++c) {
             int row; double sgn, b;
             os_get(P, act[c], row, sgn, b);
-            double part = 0.0;
-            double yc = S.sol[n + c];
-            if (row >= 0) {
-                for (int j = threadIdx.x; j < n; j += QT) {
-                    double a = sgn * P.A[(size_t)j * P.nC + row];
-                    part = fma(a, S.sol[j], part);
-                    S.res[j] = fma(-a, yc, S.res[j]);
-                }
-            } else if (threadIdx.x == 0) {
-                int j = -row - 1;
-                part = sgn * S.sol[j];
-                S.res[j] = fma(-sgn, yc, S.res[j]);
-            }
-            part = block_sum(part, S);
-            if (threadIdx.x == 0) S.res[n + c] = S.rhs[n + c] - part;
+            const int v = row < 0 ? -row - 1 : S.svar[row];
+            if (v >= 0 && vmap[v] == 0) {
+                const double a = row < 0 ? sgn : sgn * P.A[(size_t)v * P.nC + row];
+                kind[c] = v; vmap[v] = -1;
+                S.sol[v] = b / a;
+            } else { kind[c] = -1; gpos[qg++] = c; }
         }
+        int nr = 0;
+        for (int v = 0; v < n; ++v) if (vmap[v] == 0) { vmap[v] = nr; freev[nr++] = v; }
+        S.ired[2] = nr; S.ired[3] = qg;
+    }
+    __syncthreads();
+    const int nr = S.ired[2], qg = S.ired[3], Nr = nr + qg;
+    // right-hand side of the reduced system = full residual at (x_fixed, 0, y = 0)
+    kkt_residual(P, W, S, rho, gv, act, q);
+    // reduced matrix
+    for (int i = wave_id(); i < Nr; i += QW) {
+        double* kr = K + (size_t)i * Nr;
+        if (i < nr) {
+            const double* h = W.Hs + (size_t)freev[i] * n;
+            for (int j = lane_id(); j < nr; j += 64) kr[j] = h[freev[j]] + (i == j ? rho : 0.0);
+        } else {
+            int row; double sgn, b;
+            os_get(P, act[gpos[i - nr]], row, sgn, b);
+            for (int j = lane_id(); j < nr; j += 64) {
+                const int v = freev[j];
+                const double a = row >= 0 ? sgn * P.A[(size_t)v * P.nC + row] : (v == -row - 1 ? sgn : 0.0);
+                kr[j] = a;
+                K[(size_t)j * Nr + i] = a;
+            }
+            for (int j = nr + lane_id(); j < Nr; j += 64) kr[j] = 0.0;
+        }
+    }
+    __syncthreads();
+    double minpiv = Nr > 0 ? lu_factor(K, Nr, S) : 1.0;
+    if (minpiv < 1e-13) return -1;
+    for (int round = 0; round < 3; ++round) {
+        // gather the reduced residual, solve, scatter the correction
+        for (int i = threadIdx.x; i < Nr; i += QT) S.rhs[i] = i < nr ? S.res[freev[i]] : S.res[n + gpos[i - nr]];
+        if (Nr > 0) lu_solve(K, Nr, S.rhs, S);
         __syncthreads();
-        lu_solve(K, Nk, S.res, S);
-        for (int i = threadIdx.x; i < Nk; i += QT) S.sol[i] += S.res[i];
+        for (int i = threadIdx.x; i < Nr; i += QT) {
+            if (i < nr) S.sol[freev[i]] += S.rhs[i]; else S.sol[n + gpos[i - nr]] += S.rhs[i];
+        }
+        // multipliers of the fixing rows from the stationarity rows of their variables
+        for (int c = threadIdx.x; c < q; c += QT) if (kind[c] >= 0) S.sol[n + c] = 0.0;
+        __syncthreads();
+        kkt_residual(P, W, S, rho, gv, act, q);
+        for (int c = threadIdx.x; c < q; c += QT)
+            if (kind[c] >= 0) {
+                int row; double sgn, b;
+                os_get(P, act[c], row, sgn, b);
+                const int v = kind[c];
+                const double a = row < 0 ? sgn : sgn * P.A[(size_t)v * P.nC + row];
+                S.sol[n + c] = S.res[v] / a;
+            }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < n; i += QT) xo[i] = S.sol[i];
     for (int c = threadIdx.x; c < q; c += QT) uo[c] = -S.sol[n + c];
     __syncthreads();
-    // verification: stationarity (relative), worst primal violation over all rows, most negative multiplier
-    for (int i = threadIdx.x; i < n; i += QT) {
-        double s = gv[i] + rho * xo[i];
-        for (int j = 0; j < n; ++j) s = fma(W.Hs[(size_t)i * n + j], xo[j], s);
-        S.t[i] = s;
-    }
-    __syncthreads();
-    for (int c = 0; c < q; ++c) {
-        int row; double sgn, b;
-        os_get(P, act[c], row, sgn, b);
-        double uc = uo[c];
-        if (row >= 0) {
-            for (int j = threadIdx.x; j < n; j += QT) S.t[j] = fma(-sgn * P.A[(size_t)j * P.nC + row], uc, S.t[j]);
-        } else if (threadIdx.x == 0) {
-            S.t[-row - 1] -= sgn * uc;
-        }
-        __syncthreads();
-    }
+    // verification: stationarity (relative), worst primal violation over all rows, most negative
+    // multiplier.  The last kkt_residual call was made at this x with the fixing rows' multipliers
+    // zeroed: its rows of free variables are the stationarity residual (the rows of fixed variables
+    // vanish by the construction of those multipliers), and S.ax = A x.
     double stat = 0.0, scale = 1.0, dneg = 0.0, pviol = 0.0;
-    for (int i = threadIdx.x; i < n; i += QT) { stat = fmax(stat, fabs(S.t[i])); scale = fmax(scale, fabs(gv[i])); }
+    for (int i = threadIdx.x; i < n; i += QT) {
+        if (vmap[i] >= 0) stat = fmax(stat, fabs(S.res[i]));
+        scale = fmax(scale, fabs(gv[i]));
+    }
     for (int c = threadIdx.x; c < q; c += QT) { dneg = fmax(dneg, -uo[c]); scale = fmax(scale, fabs(uo[c])); }
-    rows_times(P, xo, S.ax, S.jend);
     for (int c = threadIdx.x; c < P.m1; c += QT) {
         int row; double sgn, b;
         if (!os_get(P, c, row, sgn, b)) continue;
@@ -548,13 +605,53 @@ __device__ void gi_drop(Ws& W, const Lds& S, int n, int q, int l) {
     __syncthreads();
 }
 
+// (x,u) of the working set from the factors at hand: with J'N' = [R;0] and G^-1 = JJ',
+//   y = R^-T b,  x = J1 y - J2 (J'gr)_2,  u = R^-1 (y + (J'gr)_1)        -> S.xp, S.up
+__device__ void factor_refresh(const Prob& P, const Ws& W, const Lds& S, int n, int q) {
+    rowdot(W.JT, n, S.gr, S.t);                                   // t = J' gr
+    for (int k = threadIdx.x; k < q; k += QT) {                   // y = T' b
+        int row; double sgn, b;
+        double acc = 0.0;
+        for (int i = 0; i <= k; ++i) {
+            os_get(P, S.act[i], row, sgn, b);
+            acc += W.T[(size_t)k * n + i] * b;
+        }
+        S.z[k] = acc;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += QT) S.d[j] = j < q ? S.z[j] : -S.t[j];
+    __syncthreads();
+    coldot(W.JT, n, 0, S.d, S.xp, 1.0);                           // x
+    for (int i = threadIdx.x; i < q; i += QT) {                   // u = T (y + t_1)
+        double acc = 0.0;
+        for (int k = i; k < q; ++k) acc += W.T[(size_t)k * n + i] * (S.z[k] + S.t[k]);
+        S.up[i] = acc;
+    }
+    __syncthreads();
+}
+
 // GI solve of  min 1/2 x'(Hs+rho I)x + gr'x  s.t. list.  Returns 0 ok, 1 infeasible, 2 limit.
-__device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho, int n_crash_in,
-                        int& q_out, int& iters_out, int max_iter) {
+// warm: the factors, working set (S.act, S.is_act, q_out) of the previous proximal round are still in
+// place; if its multipliers stay non-negative for the new linear term the round starts from there.
+__device__ int gi_solve(const Prob& P, Ws& W, const Lds& S, double rho, int n_crash_in,
+                        int& q_out, int& iters_out, int max_iter, bool warm) {
     const int n = P.n;
-    Ws W = W_in;
     const int n_crash = n_crash_in;
     int q = 0, iters = 0, status = 0;
+    if (warm && q_out > 0) {
+        factor_refresh(P, W, S, n, q_out);
+        double mn = 0.0;
+        for (int j = threadIdx.x; j < q_out; j += QT) mn = fmax(mn, -S.up[j]);
+        mn = block_max(mn, S);
+        if (mn > 0.0) warm = false;
+        else {
+            q = q_out;
+            for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
+            for (int j = threadIdx.x; j < q; j += QT) S.u[j] = S.up[j];
+            __syncthreads();
+        }
+    } else warm = false;
+    if (!warm) {
     for (int c = threadIdx.x; c < P.m1; c += QT) S.is_act[c] = 0;
     __syncthreads();
     // x = -G^-1 gr = -J (J' gr) with J = J0 = L^-T
@@ -600,6 +697,7 @@ __device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho,
         }
     __syncthreads();
     TOC(t_cr, 9);
+    }
     int refreshes = 0;
     for (;;) {
         TIC(t_scan);
@@ -622,26 +720,7 @@ __device__ int gi_solve(const Prob& P, const Ws& W_in, const Lds& S, double rho,
                 // u = R^-1 (y + (J'gr)_1)   (the oracle solves the same system by LU)
                 TIC(t_k0);
                 int okr = 1;
-                rowdot(W.JT, n, S.gr, S.t);                                   // t = J' gr
-                for (int k = threadIdx.x; k < q; k += QT) {                   // y = T' b
-                    int row; double sgn, b;
-                    double acc = 0.0;
-                    for (int i = 0; i <= k; ++i) {
-                        os_get(P, S.act[i], row, sgn, b);
-                        acc += W.T[(size_t)k * n + i] * b;
-                    }
-                    S.z[k] = acc;
-                }
-                __syncthreads();
-                for (int j = threadIdx.x; j < n; j += QT) S.d[j] = j < q ? S.z[j] : -S.t[j];
-                __syncthreads();
-                coldot(W.JT, n, 0, S.d, S.xp, 1.0);                           // x
-                for (int i = threadIdx.x; i < q; i += QT) {                   // u = T (y + t_1)
-                    double acc = 0.0;
-                    for (int k = i; k < q; ++k) acc += W.T[(size_t)k * n + i] * (S.z[k] + S.t[k]);
-                    S.up[i] = acc;
-                }
-                __syncthreads();
+                factor_refresh(P, W, S, n, q);
                 TOC(t_k0, 7);
                 if (okr) {
                     double mn = 0.0;
@@ -758,7 +837,8 @@ __device__ void carve(Lds& S, unsigned char* base, int n, int nC) {
     S.ax = p; p += nC; S.red = p; p += 8;
     int* ip = (int*)p;
     S.act = ip; ip += n + 2; S.crash = ip; ip += 2 * n; S.piv = ip; ip += n2; S.ired = ip; ip += 8;
-    S.jend = ip; ip += nC;
+    S.jend = ip; ip += nC; S.svar = ip; ip += nC;
+    S.kk_kind = ip; ip += n + 2; S.kk_vmap = ip; ip += n; S.kk_free = ip; ip += n; S.kk_gpos = ip; ip += n + 2;
     S.is_act = (unsigned char*)ip;
 }
 
@@ -816,7 +896,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
         }
         int status = 1, tot_iters = 0, q = 0;
         if (chol_ok) {
-            tri_inverse(L, W.J0T, n);
+            tri_inverse(L, W.J0T, n, S);
             TOC(t_ch, 8);
             // crash list: lower bounds of curvature-free variables with positive cost
             // S.hv[j] = 1 if variable j has any curvature
@@ -831,6 +911,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
                 for (int j = 0; j < n; ++j) if (P.A[(size_t)j * nC + i] != 0.0) { ++nnz; var = j; }
                 S.ax[i] = nnz == 1 ? (double)var : -1.0;
                 S.jend[i] = var + 1;
+                S.svar[i] = nnz == 1 ? var : -1;
             }
             __syncthreads();
             int n_crash = 0;
@@ -863,7 +944,7 @@ __global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
                 __syncthreads();
                 int iters = 0;
                 TIC(t_gi);
-                int rc = gi_solve(P, W, S, rho, n_crash, q, iters, 20 * (n + P.m1) + 100);
+                int rc = gi_solve(P, W, S, rho, n_crash, q, iters, 20 * (n + P.m1) + 100, it > 0);
                 TOC(t_gi, 10);
                 if (blockIdx.x == 0 && threadIdx.x == 0) { TOC(t_gi, 15); }
                 tot_iters += iters;
@@ -937,7 +1018,7 @@ size_t eepacc_qp_dense_ws_doubles(int nV) {
 size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
     const size_t n = (size_t)nV, n2 = 2 * n + 2;
     size_t dbl = 12 * n + 4 + 4 * n2 + (size_t)nC + 8;
-    size_t ints = (n + 2) + 2 * n + n2 + 8 + (size_t)nC;
+    size_t ints = (n + 2) + 2 * n + n2 + 8 + 2 * (size_t)nC + 4 * n + 4;
     size_t bytes = dbl * 8 + ints * 4 + 2 * ((size_t)nC + n) + 16;
     return (bytes + 15) & ~(size_t)15;
 }
