@@ -18,6 +18,14 @@
 
 namespace eepacc {
 
+#ifdef EEPACC_AB_TIMING
+__device__ unsigned long long g_ab_prof[16];
+#define PTIC(L) long long _pt = wall_clock64()
+#define PTOC(L, slot) do { long long _n = wall_clock64(); (L).prof[slot] += _n - _pt; _pt = _n; } while (0)
+#else
+#define PTIC(L)
+#define PTOC(L, slot)
+#endif
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 constexpr double kInf = 1e300;
@@ -142,6 +150,9 @@ struct Lane {
     double tau_rev;               // tau_{N-lane} (reversed stage order, see adjoint())
     double ba[kNumRowTypes];      // a-space right-hand sides
     unsigned valid;               // bit t: row (t, lane) exists with a non-zero normal
+#ifdef EEPACC_AB_TIMING
+    long long prof[14];
+#endif
     unsigned ign;                 // bit t / 16+g: duplicate row ignored during this solve
     unsigned long long kmask;     // wave-uniform: stages whose penalty q n n' is folded into He
     double lbF, lbS, lbV, lbH;    // slack lower bounds (constant rows of stage 0 fold in here)
@@ -207,6 +218,22 @@ __device__ __forceinline__ double hinv_mul(const double* Hs, const double* yv, i
         a3 = fma(col[(i + 3) * NS], yv[i + 3], a3);
     }
     return lane < N ? (a0 + a1) + (a2 + a3) : 0.0;
+}
+
+// two products with one pass over the table
+template <int NS>
+__device__ __forceinline__ void hinv_mul2(const double* Hs, const double* y0, const double* y1, int N, int lane,
+                                          double& o0, double& o1) {
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    const double* col = Hs + (lane & (NS - 1));
+#pragma unroll
+    for (int i = 0; i < NS; i += 2) {
+        const double h0 = col[(i + 0) * NS], h1 = col[(i + 1) * NS];
+        a0 = fma(h0, y0[i + 0], a0); b0 = fma(h0, y1[i + 0], b0);
+        a1 = fma(h1, y0[i + 1], a1); b1 = fma(h1, y1[i + 1], b1);
+    }
+    o0 = lane < N ? a0 + a1 : 0.0;
+    o1 = lane < N ? b0 + b1 : 0.0;
 }
 
 // a-space normal of the row (kq; al,be,ga,de) evaluated at this lane j:
@@ -299,13 +326,38 @@ __device__ __forceinline__ void he_load_base(double* He, const double* __restric
     }
 }
 
+// row/column of entry e of a packed lower triangle (e = r(r+1)/2 + c), one table per workgroup
+template <int MMAX>
+__device__ __forceinline__ unsigned short* rc_table() {
+    __shared__ unsigned short tab[MMAX * (MMAX + 1) / 2];
+    return tab;
+}
+template <int MMAX>
+__device__ __forceinline__ void rc_table_init() {      // every thread of the workgroup, before any returns
+    unsigned short* tab = rc_table<MMAX>();
+    for (int e = threadIdx.x; e < MMAX * (MMAX + 1) / 2; e += blockDim.x) {
+        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        tab[e] = (unsigned short)((r << 8) | (e - r * (r + 1) / 2));
+    }
+    __syncthreads();
+}
+
 // ----------------------------------------------------------------------------------------------
 // rebuild the working-set list + effective rows from the state codes, build S = C Hinv C' + D,
 // invert it in place (symmetric sweeps).  returns m (or -1 if S was numerically singular).
 template <int MMAX, int NS>
 __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* Hs, const double* tauv) {
     const int lane = L.lane, N = L.N;
+#ifdef EEPACC_AB_TIMING
+    long long _q = wall_clock64();
+#define RTOC(slot) do { long long _n = wall_clock64(); L.prof[slot] += _n - _q; _q = _n; } while (0)
+#else
+#define RTOC(slot)
+#endif
     he_sync(L, c, M, Hs, tauv);
+    RTOC(9);
     // count this lane's active rows
     int cnt = 0;
 #pragma unroll
@@ -346,65 +398,70 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
         }
     }
     WSYNC();
+    RTOC(10);
     if (m == 0) return 0;
-    // S columns: u_j = He c_j
-    for (int j = 0; j < m; ++j) {
-        const int kj = M.w_k[j];
-        double cj = normal_at(L, kj, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj]);
-        if (lane < NS) M.yv[lane] = cj;
+    // S columns: u_j = He c_j, two columns per pass (each He element is loaded once for both, and the
+    // two scan chains of the trajectories overlap).  Second set of scratch vectors: lam | ws, wv, wa,
+    // all free while the factor is rebuilt.
+    for (int j = 0; j < m; j += 2) {
+        const bool two = j + 1 < m;
+        const int kj0 = M.w_k[j], kj1 = two ? M.w_k[j + 1] : 0;
+        double c0 = normal_at(L, kj0, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj0]);
+        double c1 = two ? normal_at(L, kj1, M.e_al[j + 1], M.e_be[j + 1], M.e_ga[j + 1], M.e_de[j + 1], tauv[kj1]) : 0.0;
+        if (lane < NS) { M.yv[lane] = c0; M.lam[lane] = c1; }
         WSYNC();
-        double u = hinv_mul<NS>(Hs, M.yv, N, lane);
-        double su, vu;
-        hom_traj(L, u, su, vu);
-        if (lane < N) M.ub[lane] = u;
-        if (lane <= N) { M.sub[lane] = su; M.vub[lane] = vu; }
+        double u0, u1;
+        hinv_mul2<NS>(Hs, M.yv, M.lam, N, lane, u0, u1);
+        double su0, vu0, su1, vu1;
+        hom_traj(L, u0, su0, vu0);
+        hom_traj(L, u1, su1, vu1);
+        if (lane < N) { M.ub[lane] = u0; M.wa[lane] = u1; }
+        if (lane <= N) { M.sub[lane] = su0; M.vub[lane] = vu0; M.ws[lane] = su1; M.wv[lane] = vu1; }
         WSYNC();
         if (lane >= j && lane < m) {
             const int ki = M.w_k[lane];
-            double sx = M.e_al[lane] * M.sub[ki] + M.e_be[lane] * M.vub[ki];
-            if (ki < N) sx += M.e_ga[lane] * M.ub[ki];
-            if (ki > 0 && ki <= N) sx += M.e_de[lane] * M.ub[ki - 1];
+            const double eal = M.e_al[lane], ebe = M.e_be[lane], ega = M.e_ga[lane], ede = M.e_de[lane];
+            double sx = eal * M.sub[ki] + ebe * M.vub[ki];
+            if (ki < N) sx += ega * M.ub[ki];
+            if (ki > 0 && ki <= N) sx += ede * M.ub[ki - 1];
             M.P[pidx(lane, j)] = sx;
+            if (two && lane >= j + 1) {
+                double sy = eal * M.ws[ki] + ebe * M.wv[ki];
+                if (ki < N) sy += ega * M.wa[ki];
+                if (ki > 0 && ki <= N) sy += ede * M.wa[ki - 1];
+                M.P[pidx(lane, j + 1)] = sy;
+            }
         }
         WSYNC();
     }
+    RTOC(11);
     // in-place inversion by symmetric sweeps: after sweeping every pivot P = -S^-1
     int singular = 0;
     if (lane < m) M.sv[lane] = fabs(M.P[pidx(lane, lane)]);     // original diagonal (pivot scale)
     WSYNC();
+    // the packed lower triangle is spread over all 64 lanes (entry e = lane + 64 t; its row and column
+    // come from a small table), so a sweep costs m(m+1)/128 entry updates per lane instead of m
+    const unsigned short* rc = rc_table<MMAX>();
+    const int nnz = m * (m + 1) / 2;
     for (int k = 0; k < m; ++k) {
         const double d = M.P[pidx(k, k)];
         if (!(d > 1e-12 * M.sv[k])) { singular = 1; break; }
         const double inv = 1.0 / d;
         if (lane < m) M.colk[lane] = M.P[pidx(lane, k)];
         WSYNC();
-        if (lane < m) {
-            // lane owns column `lane` of the lower triangle: rows r = lane .. m-1 (independent updates)
-            const double cl = M.colk[lane] * inv;
-            int r = lane;
-            for (; r + 4 <= m; r += 4) {
-                const int i0 = pidx(r, lane), i1 = pidx(r + 1, lane), i2 = pidx(r + 2, lane), i3 = pidx(r + 3, lane);
-                const double p0 = M.P[i0], p1 = M.P[i1], p2 = M.P[i2], p3 = M.P[i3];
-                const double c0 = M.colk[r], c1 = M.colk[r + 1], c2 = M.colk[r + 2], c3 = M.colk[r + 3];
-                double v0 = p0 - c0 * cl, v1 = p1 - c1 * cl, v2 = p2 - c2 * cl, v3 = p3 - c3 * cl;
-                if (lane == k) { v0 = c0 * inv; v1 = c1 * inv; v2 = c2 * inv; v3 = c3 * inv; }
-                if (r == k) v0 = (lane == k) ? -inv : cl;
-                if (r + 1 == k) v1 = cl;
-                if (r + 2 == k) v2 = cl;
-                if (r + 3 == k) v3 = cl;
-                M.P[i0] = v0; M.P[i1] = v1; M.P[i2] = v2; M.P[i3] = v3;
-            }
-            for (; r < m; ++r) {
-                const int i0 = pidx(r, lane);
-                const double c0 = M.colk[r];
-                double v0 = M.P[i0] - c0 * cl;
-                if (lane == k) v0 = c0 * inv;
-                if (r == k) v0 = (lane == k) ? -inv : cl;
-                M.P[i0] = v0;
-            }
+#pragma unroll 2
+        for (int e = lane; e < nnz; e += 64) {
+            const int code = rc[e], r = code >> 8, cc = code & 255;
+            const double c0 = M.colk[r];
+            const double cl = M.colk[cc] * inv;
+            double v0 = M.P[e] - c0 * cl;
+            if (cc == k) v0 = c0 * inv;
+            if (r == k) v0 = (cc == k) ? -inv : cl;
+            M.P[e] = v0;
         }
         WSYNC();
     }
+    RTOC(12);
     if (singular) return -1;
     if (lane < m)
         for (int r = lane; r < m; ++r) M.P[pidx(r, lane)] = -M.P[pidx(r, lane)];
@@ -712,7 +769,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
     double lam_q = 0.0, best = 0.0;
     Incoming q{0, 0, 0, 0, false, 0, 0, 0, 0, 0};
     for (;;) {
+        PTIC(L);
         m = rebuild_and_factor(L, c, M, Hs, tauv);
+        PTOC(L, 0);
         if (m < 0) {
             if (!warm) { st.status = 2; break; }
             L.code = 0ull;                 // unusable warm start: cold start
@@ -736,11 +795,15 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             WSYNC();
             solve_multipliers(M, m, lane, N);
         }
+        PTOC(L, 1);
         // working accuracy while the working set is still changing; polished after convergence
         refine_primal(L, c, M, Hs, m, lam_q, q.kq, q.al, q.be, q.ga, q.de, grad_total, 3, 1e-11);
+        PTOC(L, 2);
         if (warm) {
             if (m > 0) {
-                if (warm_repair(L, c, M, m, pass < kSinglePasses)) {
+                const bool rep = warm_repair(L, c, M, m, pass < kSinglePasses);
+                PTOC(L, 3);
+                if (rep) {
                     if (++pass >= kSinglePasses + 6) {
                         L.code = 0ull;
                         he_load_base<NS>(Hs, Hbase, N, lane);
@@ -761,6 +824,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             const int relax_every = 3 * N + 30;
             const double tolv = kTolViol * (st.iters < relax_every ? 1.0 : (st.iters < 2 * relax_every ? 10.0 : (st.iters < 3 * relax_every ? 100.0 : 1000.0)));
             const int bp = find_violation(L, c, tolv, best);
+            PTOC(L, 4);
             if (bp < 0) break;
             if (++st.iters > max_iter) { st.status = 2; break; }
             q.kq = bp >> 5; q.qcode = bp & 31;
@@ -910,6 +974,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             }
         }
         if (finished) { have_q = false; lam_q = 0.0; q.al = q.be = q.ga = q.de = q.d = 0.0; }
+        PTOC(L, 5);
     }
     if (st.status == 0 && m > 0) refine_primal(L, c, M, Hs, m, 0.0, 0, 0.0, 0.0, 0.0, 0.0, grad_total, 4, 1e-14);
     st.m = m;
@@ -953,6 +1018,10 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, d
                         unsigned long long& code, StepOut& so, double& s_pred, double& v_pred,
                         const double* predp, bool pred_in_lds) {
     Lane L;
+#ifdef EEPACC_AB_TIMING
+    for (int i = 0; i < 14; ++i) L.prof[i] = 0;
+    long long _t0 = wall_clock64();
+#endif
     L.lane = lane_id(); L.N = C.N;
     const int lane = L.lane, N = C.N;
     const int kk = lane <= N ? lane : N;
@@ -1040,7 +1109,15 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, d
     he_load_base<NS>(Hs, C.Hinv, N, lane);
     L.kmask = 0ull;
     WSYNC();
+#ifdef EEPACC_AB_TIMING
+    L.prof[6] += wall_clock64() - _t0;
+    _t0 = wall_clock64();
+#endif
     SolveStats st = solve_qp<MMAX, NS>(L, c, M, Hs, C.Hinv, C.tau, C.max_iter, grad_total);
+#ifdef EEPACC_AB_TIMING
+    L.prof[8] += wall_clock64() - _t0;
+    _t0 = wall_clock64();
+#endif
     code = L.code;
     // recover z = Psi x + d (A7): predicted states
     s_pred = sf + L.sh; v_pred = vf + L.vh;
@@ -1085,6 +1162,11 @@ __device__ __forceinline__ void ab_step(const DevCfg& C, WaveMem<MMAX, NS>& M, d
 #else
     so.iters = st.iters;
 #endif
+#ifdef EEPACC_AB_TIMING
+    L.prof[7] += wall_clock64() - _t0;
+    if (L.lane == 0)
+        for (int i = 0; i < 14; ++i) atomicAdd(&g_ab_prof[i], (unsigned long long)L.prof[i]);
+#endif
 }
 
 // receding-horizon shift of the working set: stage k takes stage k+1's codes, the last stage and
@@ -1122,6 +1204,7 @@ k_ab_step(const DevCfg* __restrict__ Cp, int B,
           int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
+    rc_table_init<MMAX>();
     const int b = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (b >= B) return;
     double* Hs;
@@ -1159,6 +1242,7 @@ k_run_abmpc(const DevCfg* __restrict__ Cp, int B, int k_start, int n_steps,
             int* __restrict__ work_counter, int* __restrict__ done, int kChunkSteps) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *Cp;
+    rc_table_init<MMAX>();
     double* Hs;
     WaveMem<MMAX, NS>& M = *wave_mem<MMAX, NS>(smem, C.N, Hs);
     const int lane = lane_id();
@@ -1311,6 +1395,15 @@ static int waves_per_block() {
     return w;
 }
 
+#ifdef EEPACC_AB_TIMING
+extern "C" int eepacc_debug_ab_prof(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ab_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ab_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 size_t ab_smem_bytes(int N) {
     return N <= kNSSmall ? wave_bytes(sizeof(WaveMem<kMMaxSmall, kNSSmall>), kNSSmall) * waves_per_block()
                          : wave_bytes(sizeof(WaveMem<kMMaxLarge, kNSLarge>), kNSLarge) * 2;
@@ -1382,7 +1475,7 @@ hipError_t set_max_smem() {
                           reinterpret_cast<const void*>(&k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&k_run_abmpc<kMMaxLarge, kNSLarge, 2>)};
     for (int i = 0; i < 6; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // the rest holds the static index table
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
