@@ -236,6 +236,23 @@ __device__ __forceinline__ void hinv_mul2(const double* Hs, const double* y0, co
     o1 = lane < N ? b0 + b1 : 0.0;
 }
 
+// four products with one pass over the table
+template <int NS>
+__device__ __forceinline__ void hinv_mul4(const double* Hs, const double* y0, const double* y1, const double* y2,
+                                          const double* y3, int N, int lane, double (&o)[4]) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    const double* col = Hs + (lane & (NS - 1));
+#pragma unroll
+    for (int i = 0; i < NS; i += 2) {
+        if ((i & 7) == 0) __builtin_amdgcn_sched_barrier(0);      // bound the number of loads in flight (registers)
+        const double h0 = col[(i + 0) * NS], h1 = col[(i + 1) * NS];
+        a0 = fma(h0, y0[i], a0); a1 = fma(h0, y1[i], a1); a2 = fma(h0, y2[i], a2); a3 = fma(h0, y3[i], a3);
+        b0 = fma(h1, y0[i + 1], b0); b1 = fma(h1, y1[i + 1], b1); b2 = fma(h1, y2[i + 1], b2); b3 = fma(h1, y3[i + 1], b3);
+    }
+    const bool in = lane < N;
+    o[0] = in ? a0 + b0 : 0.0; o[1] = in ? a1 + b1 : 0.0; o[2] = in ? a2 + b2 : 0.0; o[3] = in ? a3 + b3 : 0.0;
+}
+
 // a-space normal of the row (kq; al,be,ga,de) evaluated at this lane j:
 __device__ __forceinline__ double normal_at(const Lane& L, int kq, double al, double be, double ga, double de, double tau_kq) {
     double c = 0.0;
@@ -400,37 +417,33 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     WSYNC();
     RTOC(10);
     if (m == 0) return 0;
-    // S columns: u_j = He c_j, two columns per pass (each He element is loaded once for both, and the
-    // two scan chains of the trajectories overlap).  Second set of scratch vectors: lam | ws, wv, wa,
-    // all free while the factor is rebuilt.
-    for (int j = 0; j < m; j += 2) {
-        const bool two = j + 1 < m;
-        const int kj0 = M.w_k[j], kj1 = two ? M.w_k[j + 1] : 0;
-        double c0 = normal_at(L, kj0, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj0]);
-        double c1 = two ? normal_at(L, kj1, M.e_al[j + 1], M.e_be[j + 1], M.e_ga[j + 1], M.e_de[j + 1], tauv[kj1]) : 0.0;
-        if (lane < NS) { M.yv[lane] = c0; M.lam[lane] = c1; }
-        WSYNC();
-        double u0, u1;
-        hinv_mul2<NS>(Hs, M.yv, M.lam, N, lane, u0, u1);
-        double su0, vu0, su1, vu1;
-        hom_traj(L, u0, su0, vu0);
-        hom_traj(L, u1, su1, vu1);
-        if (lane < N) { M.ub[lane] = u0; M.wa[lane] = u1; }
-        if (lane <= N) { M.sub[lane] = su0; M.vub[lane] = vu0; M.ws[lane] = su1; M.wv[lane] = vu1; }
-        WSYNC();
-        if (lane >= j && lane < m) {
-            const int ki = M.w_k[lane];
-            const double eal = M.e_al[lane], ebe = M.e_be[lane], ega = M.e_ga[lane], ede = M.e_de[lane];
-            double sx = eal * M.sub[ki] + ebe * M.vub[ki];
-            if (ki < N) sx += ega * M.ub[ki];
-            if (ki > 0 && ki <= N) sx += ede * M.ub[ki - 1];
-            M.P[pidx(lane, j)] = sx;
-            if (two && lane >= j + 1) {
-                double sy = eal * M.ws[ki] + ebe * M.wv[ki];
-                if (ki < N) sy += ega * M.wa[ki];
-                if (ki > 0 && ki <= N) sy += ede * M.wa[ki - 1];
-                M.P[pidx(lane, j + 1)] = sy;
-            }
+    // S columns: u_j = He c_j, two columns per pass: each He element is loaded once for both products,
+    // the scan chains of the two trajectories overlap, and row i picks the images at its stage with
+    // lane shuffles (no LDS round trip).  Input vectors in yv | lam (free while the factor is rebuilt).
+    {
+        const int ki = lane < m ? M.w_k[lane] : 0;
+        const int kim1 = ki > 0 ? ki - 1 : 0;
+        const double eal = lane < m ? M.e_al[lane] : 0.0, ebe = lane < m ? M.e_be[lane] : 0.0;
+        const double ega = (lane < m && ki < N) ? M.e_ga[lane] : 0.0;
+        const double ede = (lane < m && ki > 0 && ki <= N) ? M.e_de[lane] : 0.0;
+        for (int j = 0; j < m; j += 2) {
+            const bool two = j + 1 < m;
+            const int j1 = two ? j + 1 : j;
+            const int kj0 = M.w_k[j], kj1 = M.w_k[j1];
+            const double c0 = normal_at(L, kj0, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], tauv[kj0]);
+            const double c1 = normal_at(L, kj1, M.e_al[j1], M.e_be[j1], M.e_ga[j1], M.e_de[j1], tauv[kj1]);
+            if (lane < NS) { M.yv[lane] = c0; M.lam[lane] = c1; }
+            WSYNC();
+            double u0, u1;
+            hinv_mul2<NS>(Hs, M.yv, M.lam, N, lane, u0, u1);
+            WSYNC();
+            double su0, vu0, su1, vu1;
+            hom_traj(L, u0, su0, vu0);
+            hom_traj(L, u1, su1, vu1);
+            const double sx = eal * __shfl(su0, ki, 64) + ebe * __shfl(vu0, ki, 64) + ega * __shfl(u0, ki, 64) + ede * __shfl(u0, kim1, 64);
+            const double sy = eal * __shfl(su1, ki, 64) + ebe * __shfl(vu1, ki, 64) + ega * __shfl(u1, ki, 64) + ede * __shfl(u1, kim1, 64);
+            if (lane >= j && lane < m) M.P[pidx(lane, j)] = sx;
+            if (two && lane >= j + 1 && lane < m) M.P[pidx(lane, j + 1)] = sy;
         }
         WSYNC();
     }
