@@ -364,8 +364,14 @@ __device__ __forceinline__ void rc_table_init() {      // every thread of the wo
 // ----------------------------------------------------------------------------------------------
 // rebuild the working-set list + effective rows from the state codes, build S = C Hinv C' + D,
 // invert it in place (symmetric sweeps).  returns m (or -1 if S was numerically singular).
+// fast = 1: the last event appended the plain row (kq, tq) whose column sv = C u, rv = P sv and pivot
+// zz = c'u - sv'rv are still in LDS -> bordered update of P;  fast = 2: it dropped the row at list
+// position drop_pos -> rank-one downdate;  fast = 0 (or any inconsistency): full rebuild.
+struct FastInfo { int fast, m_old, kq, tq, drop_pos; double zz; };
+
 template <int MMAX, int NS>
-__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* Hs, const double* tauv) {
+__device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem<MMAX, NS>& M, double* Hs, const double* tauv,
+                                                  const FastInfo& F) {
     const int lane = L.lane, N = L.N;
 #ifdef EEPACC_AB_TIMING
     long long _q = wall_clock64();
@@ -417,6 +423,57 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     WSYNC();
     RTOC(10);
     if (m == 0) return 0;
+    const unsigned short* rc = rc_table<MMAX>();
+    if (F.fast == 1 && m == F.m_old + 1 && F.m_old > 0) {
+        // position of the new row in the new (lane-major) list
+        int pl = 0;
+#pragma unroll
+        for (int t = 0; t < kNumRowTypes; ++t) pl += (t < F.tq && code_of(L, t) == 1) ? 1 : 0;
+        const int p = __builtin_amdgcn_readlane(L.base + pl, __builtin_amdgcn_readfirstlane(F.kq));
+        const double iz = 1.0 / F.zz;
+        const int nnz = m * (m + 1) / 2;
+        // in place, highest entries first: an entry moves to a higher packed index, so a chunk never
+        // overwrites what a later (lower) chunk still has to read
+        for (int e0 = ((nnz - 1) >> 6) << 6; e0 >= 0; e0 -= 64) {
+            const int e = e0 + lane;
+            double v = 0.0;
+            if (e < nnz) {
+                const int code = rc[e], r = code >> 8, cc = code & 255;
+                const int i = r < p ? r : r - 1, j = cc < p ? cc : cc - 1;
+                if (r == p && cc == p) v = iz;
+                else if (r == p) v = -M.rv[j] * iz;
+                else if (cc == p) v = -M.rv[i] * iz;
+                else v = M.P[pidx(i, j)] + M.rv[i] * M.rv[j] * iz;
+            }
+            WSYNC();
+            if (e < nnz) M.P[e] = v;
+            WSYNC();
+        }
+        RTOC(12);
+        return m;
+    }
+    if (F.fast == 2 && m == F.m_old - 1) {
+        const int p = F.drop_pos, mo = F.m_old;
+        if (lane < mo) M.colk[lane] = M.P[pidx(lane, p)];
+        WSYNC();
+        const double ip = 1.0 / M.colk[p];
+        const int nnz = m * (m + 1) / 2;
+        // lowest entries first: an entry moves to a lower packed index
+        for (int e0 = 0; e0 < nnz; e0 += 64) {
+            const int e = e0 + lane;
+            double v = 0.0;
+            if (e < nnz) {
+                const int code = rc[e], r = code >> 8, cc = code & 255;
+                const int i = r < p ? r : r + 1, j = cc < p ? cc : cc + 1;
+                v = M.P[pidx(i, j)] - M.colk[i] * M.colk[j] * ip;
+            }
+            WSYNC();
+            if (e < nnz) M.P[e] = v;
+            WSYNC();
+        }
+        RTOC(12);
+        return m;
+    }
     // S columns: u_j = He c_j, two columns per pass: each He element is loaded once for both products,
     // the scan chains of the two trajectories overlap, and row i picks the images at its stage with
     // lane shuffles (no LDS round trip).  Input vectors in yv | lam (free while the factor is rebuilt).
@@ -454,7 +511,6 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const Cfg& c, WaveMem
     WSYNC();
     // the packed lower triangle is spread over all 64 lanes (entry e = lane + 64 t; its row and column
     // come from a small table), so a sweep costs m(m+1)/128 entry updates per lane instead of m
-    const unsigned short* rc = rc_table<MMAX>();
     const int nnz = m * (m + 1) / 2;
     for (int k = 0; k < m; ++k) {
         const double d = M.P[pidx(k, k)];
@@ -781,9 +837,20 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
     int pass = 0;
     double lam_q = 0.0, best = 0.0;
     Incoming q{0, 0, 0, 0, false, 0, 0, 0, 0, 0};
+    FastInfo F{0, 0, 0, 0, 0, 1.0};   // what the last event did to the working set (see rebuild_and_factor)
+    int fast_run = 0;
     for (;;) {
         PTIC(L);
-        m = rebuild_and_factor(L, c, M, Hs, tauv);
+#ifdef EEPACC_AB_TIMING
+        L.prof[13] += 1; if (F.fast == 1) L.prof[3] += 1000000; if (F.fast == 2) L.prof[4] += 1000000;
+#endif
+        // the incremental updates are exact in exact arithmetic; a full rebuild every few of them keeps
+        // rounding from accumulating (the refinement below absorbs what is left)
+        if (F.fast != 0 && ++fast_run > 6) F.fast = 0;
+        if (F.fast == 0) fast_run = 0;
+        F.m_old = m;
+        m = rebuild_and_factor(L, c, M, Hs, tauv, F);
+        F.fast = 0;
         PTOC(L, 0);
         if (m < 0) {
             if (!warm) { st.status = 2; break; }
@@ -944,6 +1011,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
         bool finished = false;
         if (t2 <= t1) {
             // full step: the incoming constraint becomes active
+            if (!q.is_bound && m > 0) { F.fast = 1; F.kq = kq; F.tq = q.tq; F.zz = zz; }
             if (lane == kq) {
                 if (!q.is_bound) set_code(L, q.tq, 1);
                 else if (q.gq == G_H) set_code(L, R_HWP, 1);      // penalised row turns rigid
@@ -952,7 +1020,14 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const Cfg& c, WaveMem<MM
             finished = true;
         } else {
             const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
-            if (ek == EV_DROP) { if (lane == el) set_code(L, et, 0); }
+            if (ek == EV_DROP) {
+                int pl = 0;
+#pragma unroll
+                for (int t = 0; t < kNumRowTypes; ++t) pl += (t < et && code_of(L, t) == 1) ? 1 : 0;
+                F.drop_pos = __builtin_amdgcn_readlane(L.base + pl, __builtin_amdgcn_readfirstlane(el));
+                F.fast = 2;
+                if (lane == el) set_code(L, et, 0);
+            }
             else if (ek == EV_COMPL) { if (lane == el) set_code(L, et, 3); }
             else if (ek == EV_DROPH) { if (lane == el) set_code(L, et, 0); finished = true; }
             else if (ek == EV_CAPIN) { if (lane == el) set_code(L, R_HWP, 3); finished = true; }
