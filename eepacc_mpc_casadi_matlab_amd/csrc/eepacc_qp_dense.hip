@@ -842,7 +842,7 @@ __device__ void carve(Lds& S, unsigned char* base, int n, int nC) {
     S.is_act = (unsigned char*)ip;
 }
 
-__global__ void __launch_bounds__(QT) k_qp_dense(eepacc_qp_args a) {
+__global__ void __launch_bounds__(QT, 2) k_qp_dense(eepacc_qp_args a) {     // two workgroups per CU: 256 VGPRs, no scratch
     extern __shared__ __align__(16) unsigned char smem[];
     const int n = a.nV, nC = a.nC;
     Lds S;
