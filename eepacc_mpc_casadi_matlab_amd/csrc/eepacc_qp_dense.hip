@@ -717,7 +717,7 @@ __device__ int gi_solve(const Prob& P, Ws& W, const Lds& S, double rho, int n_cr
                 // refresh (x,u) from the working set -- guards against drift accumulated over many
                 // rank-one steps.  The regularised KKT system is solved through the factors at hand:
                 // with J'N' = [R;0] and G^-1 = JJ':  y = R^-T b,  x = J1 y - J2 (J'gr)_2,
-                // u = R^-1 (y + (J'gr)_1)   (the oracle solves the same system by LU)
+                // u = R^-1 (y + (J'gr)_1)   (mathematically the LU solve of that KKT system)
                 TIC(t_k0);
                 int okr = 1;
                 factor_refresh(P, W, S, n, q);
