@@ -5,7 +5,7 @@
 namespace eepacc {
 
 constexpr int kWave = 64;
-constexpr int kMaxKnots = 32;     // route table knots kept in the device config
+constexpr int kMaxKnots = 64;     // route table knots kept in the device config (use case 11 needs 42)
 constexpr int kMaxStops = 16;
 constexpr int kMaxTL = 8;
 constexpr int kMaxN = 63;         // stage k lives on lane k, terminal stage on lane N

@@ -144,6 +144,56 @@ def GenerateUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
     return OPT
 
 
+def GetUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
+    """ABO/Functions/Settings/GetUseCase.m:12-227: the predefined use cases (route tables, initial
+    speed, simulated time, cut-off distance).  Cases 8 and 9 replay a recorded lead vehicle from a
+    measurement file that is not part of this repository's fixtures."""
+    n = int(OPT["useCaseNum"])
+    E3, E4 = np.zeros((0, 3)), np.zeros((0, 4))
+    kmh = 1 / 3.6
+    cases = {
+        1: dict(speedLimZones=[[80, 0]], generateTVMPC=True, cutOffDist=300, t_sim=30),
+        2: dict(v_init=80 * kmh, speedLimZones=[[80, 0]], stopLoc=[300], generateTVMPC=True, cutOffDist=300, t_sim=40),
+        3: dict(v_init=80 * kmh, speedLimZones=[[80, 0], [120, 100], [80, 500], [30, 700], [80, 900]],
+                generateTVMPC=True, cutOffDist=1200, t_sim=100),
+        4: dict(v_init=0.0, speedLimZones=[[80, 0]], stopLoc=[500], generateTVMPC=True, cutOffDist=900, t_sim=75),
+        5: dict(v_init=80 * kmh, speedLimZones=[[80, 0]],
+                TLLoc=[[250, 9, 17, 12], [580, 18, 10, 15], [750, 1, 15, 10]], generateTVMPC=True, cutOffDist=850, t_sim=75),
+        6: dict(speedLimZones=[[80, 0]], curves=[[-1 / 20, 100, 130], [1 / 40, 170, 230], [-1 / 80, 230, 250]],
+                generateTVMPC=True, cutOffDist=400, t_sim=40),
+        7: dict(v_init=58 * kmh, speedLimZones=[[60, 0]],
+                slopes=[[0, 1, 300]] + [[k, 290 + 10 * k, 300 + 10 * k] for k in range(1, 9)],
+                stopLoc=[600], generateTVMPC=True, cutOffDist=700, t_sim=70),
+        10: dict(t_sim=60, speedLimZones=[[120, 0]], IncludeTV=False, generateTVMPC=False, TV_cuttingDist=30.0,
+                 TV_cuttingVel=100 * kmh, v_init=120 * kmh, cutOffDist=1500),
+        11: dict(v_init=0.0, speedLimZones=[[30, 0], [50, 600], [80, 1000], [120, 4450], [80, 10700]],
+                 curves=[[-1 / 2, 200, 206], [-1 / 9, 2600, 2605], [1 / 17, 2605, 2650], [-1 / 12, 2650, 2655],
+                         [-1 / 9, 3400, 3405], [1 / 17, 3405, 3450], [-1 / 12, 3450, 3455], [-1 / 30, 4300, 4310],
+                         [-1 / 52, 4400, 4460], [-1 / 75, 7900, 8253]],
+                 stopLoc=[80, 450, 600, 4000, 10700], cutOffDist=11.5e3, t_sim=700, generateTVMPC=False),
+        12: dict(t_sim=100, v_init=0.0, speedLimZones=[[100, 0], [80, 300], [50, 510]], slopes=[[0, 200, 300]],
+                 curves=[[-1 / 30, 220, 300], [1 / 20, 400, 430]], stopLoc=[350, 500],
+                 TLLoc=[[450, 0, 15, 10], [250, 8, 15, 10]], cutOffDist=500, generateTVMPC=False),
+    }
+    if n in (8, 9):
+        raise NotImplementedError("use cases 8 and 9 replay 'ArgonneData/61505019 Test Data.txt' (GetUseCase.m:103-146), "
+                                  "a measurement file outside this repository's fixtures")
+    if n not in cases:
+        raise ValueError("unknown use case!")                               # GetUseCase.m:225
+    uc = dict(slopes=E3, curves=E3, stopLoc=np.zeros(0), TLLoc=E4)
+    uc.update(cases[n])
+    for k in ("speedLimZones", "slopes", "curves", "TLLoc"):
+        uc[k] = np.asarray(uc[k], dtype=np.float64).reshape(-1, 4 if k == "TLLoc" else (2 if k == "speedLimZones" else 3))
+    uc["stopLoc"] = np.asarray(uc["stopLoc"], dtype=np.float64).ravel()
+    OPT.update(uc)
+    if n == 10:                                                             # :148-163 lead vehicle cutting in
+        Ts = OPT["Tvec"][0]
+        k_tot = int(round(OPT["t_sim"] / Ts)) + 1
+        OPT["s_tv"] = OPT["TV_cuttingDist"] + OPT["TV_cuttingVel"] * Ts * np.arange(k_tot)
+        OPT["v_tv"] = OPT["TV_cuttingVel"] * np.ones(k_tot)
+    return OPT
+
+
 def default_opt() -> Dict[str, Any]:
     """The script-level settings of ABO/Main.m:22-53."""
     return dict(createGifs=False, IncludeTV=True, useCaseNum=0, Ts=0.5, t_sim=435.0)
@@ -183,7 +233,7 @@ def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 
         OPT.setdefault("TLLoc", np.zeros((0, 4)))
         OPT.setdefault("cutOffDist", 3.5e3)
     else:
-        raise NotImplementedError("GetUseCase.m canned use cases are out of scope (SURVEY 8f)")
+        OPT = GetUseCase(OPT)                                                # :195-198
     OPT.update(h_min=2.0, tau_min=0.5)                                       # :203-204
     OPT.update(TVlength=4.0, TVinitDist=10.0, TVinitVel=0.0, TV_N_hor=20, TV_Ts=0.5)  # :207-212
     OPT.update(stopVel=0.2, stopRefDist=100.0, stopRefVelSlope=1.0, TLStopRegionSize=2.0,
