@@ -144,10 +144,24 @@ def GenerateUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
     return OPT
 
 
+def TimeVelToDist(t, v, s0: float, M: int) -> np.ndarray:
+    """ABO/Functions/Other/TimeVelToDist.m:15-33: M-step forward Euler distance of a speed trace."""
+    t = np.asarray(t, dtype=np.float64); v = np.asarray(v, dtype=np.float64)
+    s = np.zeros(t.size)
+    s[0] = s0
+    for i in range(t.size - 1):
+        DT = (t[i + 1] - t[i]) / M
+        s_ = s[i]
+        for _ in range(M):
+            s_ = s_ + DT * v[i]
+        s[i + 1] = s_
+    return s
+
+
 def GetUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
     """ABO/Functions/Settings/GetUseCase.m:12-227: the predefined use cases (route tables, initial
-    speed, simulated time, cut-off distance).  Cases 8 and 9 replay a recorded lead vehicle from a
-    measurement file that is not part of this repository's fixtures."""
+    speed, simulated time, cut-off distance).  Cases 8 and 9 replay a recorded lead vehicle: the caller
+    passes the two columns of the measurement file as OPT["argonne_lead"] = (t, v_mph)."""
     n = int(OPT["useCaseNum"])
     E3, E4 = np.zeros((0, 3)), np.zeros((0, 4))
     kmh = 1 / 3.6
@@ -175,9 +189,11 @@ def GetUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
                  curves=[[-1 / 30, 220, 300], [1 / 20, 400, 430]], stopLoc=[350, 500],
                  TLLoc=[[450, 0, 15, 10], [250, 8, 15, 10]], cutOffDist=500, generateTVMPC=False),
     }
-    if n in (8, 9):
-        raise NotImplementedError("use cases 8 and 9 replay 'ArgonneData/61505019 Test Data.txt' (GetUseCase.m:103-146), "
-                                  "a measurement file outside this repository's fixtures")
+    cases[8] = dict(t_sim=110, speedLimZones=[[120, 0]], IncludeTV=True, generateTVMPC=False, cutOffDist=800)
+    cases[9] = dict(t_sim=270, v_init=120 * kmh, speedLimZones=[[150, 0]], IncludeTV=True, generateTVMPC=False, cutOffDist=8e3)
+    if n in (8, 9) and "argonne_lead" not in OPT:
+        raise ValueError("use cases 8 and 9 replay the recorded lead vehicle of 'ArgonneData/61505019 Test Data.txt' "
+                         "(GetUseCase.m:103-146): pass its time [s] / speed [mph] columns as OPT['argonne_lead'] = (t, v_mph)")
     if n not in cases:
         raise ValueError("unknown use case!")                               # GetUseCase.m:225
     uc = dict(slopes=E3, curves=E3, stopLoc=np.zeros(0), TLLoc=E4)
@@ -186,6 +202,15 @@ def GetUseCase(OPT: Dict[str, Any]) -> Dict[str, Any]:
         uc[k] = np.asarray(uc[k], dtype=np.float64).reshape(-1, 4 if k == "TLLoc" else (2 if k == "speedLimZones" else 3))
     uc["stopLoc"] = np.asarray(uc["stopLoc"], dtype=np.float64).ravel()
     OPT.update(uc)
+    if n in (8, 9):                                                         # :103-146 recorded lead vehicle
+        t_all, v_all = (np.asarray(x, dtype=np.float64) for x in OPT["argonne_lead"])
+        t_start, gap = (4720.0, 20.0) if n == 8 else (4400.0, 50.0)
+        use = (t_all >= t_start) & (t_all < t_start + OPT["t_sim"])
+        t_tv, v_tv = t_all[use], v_all[use] * 0.44704
+        s_tv = TimeVelToDist(t_tv, v_tv, OPT["s_init"] + gap, 5)
+        f = int(round(OPT["Tvec"][0] / (t_tv[1] - t_tv[0])))
+        OPT["s_tv"] = np.concatenate([s_tv[::f], s_tv[-1:]])
+        OPT["v_tv"] = np.concatenate([v_tv[::f], v_tv[-1:]])
     if n == 10:                                                             # :148-163 lead vehicle cutting in
         Ts = OPT["Tvec"][0]
         k_tot = int(round(OPT["t_sim"] / Ts)) + 1

@@ -242,19 +242,22 @@ def test_variable_time_steps(torch_mod, lead_trace):
             assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (i, n)
 
 
-@pytest.mark.parametrize("case", [1, 2, 3, 4, 5, 6, 7, 10, 11, 12])
+@pytest.mark.parametrize("case", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_reference_use_cases(case, torch_mod):
     """The predefined use cases of GetUseCase.m (route tables of Settings.m's useCaseNum switch), no
-    lead vehicle (s_tv = inf, Main.m:77-80) except the cut-in scenario 10: closed loop against the
+    lead vehicle (s_tv = inf, Main.m:77-80) except the recorded leads of 8, 9 and the cut-in scenario 10: closed loop against the
     oracle over the use case's own simulated time.  ORIG tree: its ABMPC has the speed-limit / curve /
     stop / traffic-light rows (ABO's CreateQP_AB.m:324-346 has them commented out)."""
     from oracle import Oracle
     from eepacc_mpc_casadi_matlab_amd.settings import Settings, SetVehicleParameters, default_opt
     o = default_opt(); o["useCaseNum"] = case
+    if case in (8, 9):      # recorded lead vehicle (fixture extracted by tools/make_golden.py)
+        rec = load_golden("argonne_61505019_lead")
+        o["argonne_lead"] = (rec["t"], rec["v_mph"])
     OPT = Settings(o, tree="ORIG", N_hor=20)
     V = SetVehicleParameters("ORIG")
     n_steps = int(round(OPT["t_sim"] / OPT["Tvec"][0])) + 1
-    if case == 10:
+    if case in (8, 9, 10):
         s_tv, v_tv = np.asarray(OPT["s_tv"], dtype=np.float64), np.asarray(OPT["v_tv"], dtype=np.float64)
     else:
         s_tv, v_tv = np.full(n_steps, np.inf), np.zeros(n_steps)
