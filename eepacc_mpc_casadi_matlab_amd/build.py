@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeepacc.so")
 SOURCES = ["eepacc_kernels.hip", "eepacc_qp_dense.hip", "eepacc_fb.hip", "eepacc_capi.cpp"]
-HEADERS = ["eepacc_device.h", "eepacc_qp_dense.h", "eepacc_fb.h", "eepacc_stage.h", os.path.join("..", "..", "include", "eepacc.h")]
+HEADERS = ["eepacc_device.h", "eepacc_qp_dense.h", "eepacc_fb.h", "eepacc_stage.h", "eepacc_ab_impl.inc", os.path.join("..", "..", "include", "eepacc.h")]
 
 
 def is_stale() -> bool:

@@ -14,11 +14,11 @@
 
 namespace eepacc {
 size_t ab_smem_bytes(int N);
-hipError_t launch_ab_step(const DevCfg* dC, int N, int B, const double* s, const double* v, const double* a_prev,
+hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream);
-hipError_t launch_run_abmpc(const DevCfg* dC, int N, int B, int k_start, int n_steps, const double* s0,
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
                             int32_t* status, int32_t* iters_total, int* work_counter, int* done, int num_cus,
@@ -114,7 +114,24 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         if (S->Tvec[k] != S->Tvec[0]) C.const_T = 0;
         if (S->Mb && S->Mb[k] != 0) C.mb_any = 1;
     }
-    if (C.mb_any) return fail(EEPACC_ENOTSUP, "move blocking (Mb != 0, ABO/Settings.m:243-250) is not built yet");
+    if (C.mb_any) {
+        // block structure: stage k with Mb[k] = 1 repeats the acceleration of the previous stage
+        if (S->Mb[0] != 0) return fail(EEPACC_EINVAL, "Mb[0] must be 0 (the first stage has no predecessor in the horizon)");
+        int maxlen = 1;
+        for (int k = 0, lead = 0; k < N; ++k) {
+            if (S->Mb[k] != 0 && S->Mb[k] != 1) return fail(EEPACC_EINVAL, "Mb entries must be 0 or 1");
+            if (S->Mb[k] == 0) lead = k;
+            C.mb_lead[k] = lead;
+            C.mb_end[lead] = k;
+            if (k - lead + 1 > maxlen) maxlen = k - lead + 1;
+        }
+        for (int k = 0; k < N; ++k) if (C.mb_lead[k] != k) C.mb_end[k] = k;
+        C.mb_lead[N] = N; C.mb_end[N] = N;
+        C.mb_maxlen = maxlen;
+    } else {
+        for (int k = 0; k <= N; ++k) { C.mb_lead[k] = k; C.mb_end[k] = k; }
+        C.mb_maxlen = 1;
+    }
     C.w_FC = S->ab_fuel_term ? S->W_AB[0] : 0.0;
     C.w_a = S->W_AB[1]; C.w_j = S->W_AB[2]; C.w_v = S->W_AB[3]; C.w_h = S->W_AB[4]; C.w_s = S->W_AB[5]; C.w_f = S->W_AB[6];
     if (!(C.w_a > 0.0) || !(C.w_h > 0.0) || C.w_v < 0 || C.w_s < 0 || C.w_f < 0 || C.w_j < 0)
@@ -167,6 +184,15 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
             H[(size_t)k * N + (k - 1)] -= qj;
             H[(size_t)(k - 1) * N + k] -= qj;
         }
+    }
+    if (C.mb_any) {
+        // reduced variables (one acceleration per block): Hbar = E'HE on the leaders, identity on the rest
+        std::vector<long double> Hb((size_t)N * N, 0.0L);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j)
+                Hb[(size_t)C.mb_lead[i] * N + C.mb_lead[j]] += H[(size_t)i * N + j];
+        for (int k = 0; k < N; ++k) if (C.mb_lead[k] != k) Hb[(size_t)k * N + k] = 1.0L;
+        H.swap(Hb);
     }
     if (!spd_inverse(H, N)) return fail(EEPACC_EINVAL, "condensed Hessian is not positive definite");
     Hinv.assign((size_t)N * N, 0.0);
@@ -272,7 +298,7 @@ extern "C" int eepacc_ab_step(eepacc_handle* h, int B, const double* s, const do
         return fail(EEPACC_EINVAL, "eepacc_ab_step: NULL buffer");
     HIPCHK(hipSetDevice(h->device));
     h->last_B = B;
-    HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
+    HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, h->cfg.mb_any != 0, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
                                   s_pred, v_pred, status, h->d_iters, (hipStream_t)stream));
     return EEPACC_OK;
 }
@@ -289,7 +315,7 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
     if (h->k_done > 0 && h->carry_B != B)
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");
     h->last_B = B;
-    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
+    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, h->cfg.mb_any != 0, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
                                     h->d_carry, h->d_codes, traj, status, h->d_iters, h->d_counter, h->d_done, h->num_cus,
                                     (hipStream_t)stream));
     h->k_done += n_steps; h->carry_B = B;
@@ -392,6 +418,7 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
 static int fb_prepare(eepacc_handle* h, int B) {
     const int N = h->cfg.N;
     const size_t nV = 6 * (size_t)N, nC = 26 * (size_t)N + 2;
+    if (h->cfg.mb_any) return fail(EEPACC_ENOTSUP, "FBMPC: move blocking (Mb != 0, ABO/Settings.m:243-250) is not built yet");
     if (nV > EEPACC_QP_MAX_NV || nC > EEPACC_QP_MAX_NC || eepacc_qp_dense_lds_bytes((int)nV, (int)nC) > 160 * 1024)
         return fail(EEPACC_ENOTSUP, "FBMPC: horizon too long for the dense QP operator");
     if (B <= h->fb_B) return EEPACC_OK;

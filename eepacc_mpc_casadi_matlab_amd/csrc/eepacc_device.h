@@ -30,7 +30,7 @@ struct DevCfg {
     int32_t N_integratePlant;
     int32_t const_T;              // 1: all Tvec equal
     int32_t const_slope;          // 1: slope table is constant -> theta fixed
-    int32_t mb_any;               // move blocking requested (unsupported by the kernels)
+    int32_t mb_any;               // move blocking requested (ABO/Settings.m:243-250): a_k = a_{k-1} where Mb[k] = 1
     int32_t max_iter;
     double Tvec[kMaxN + 1];
     double tau[kMaxN + 2];        // tau[k] = sum_{i<k} Tvec[i]
@@ -60,6 +60,8 @@ struct DevCfg {
     int32_t FBuseTaylor, fb_pad;
     const double* Hinv;           // device, [N][N] row-major, inverse of the a-space Hessian
     double* pred;                 // device, [max_batch][2][64]: previous predicted s, v (paramEstSetting 2)
+    // move blocking: stage k takes the acceleration of its block leader mb_lead[k]; a leader's block ends at mb_end[k]
+    int32_t mb_lead[kMaxN + 1], mb_end[kMaxN + 1], mb_maxlen, mb_pad;
 };
 
 }  // namespace eepacc

@@ -71,8 +71,8 @@ def test_settings_validation_messages(lib):
         holder = SettingsHolder(o)
         h = C.c_void_p()
         assert lib.eepacc_create(C.byref(h), C.byref(holder.pod), C.byref(veh), 0, 16) == code
-    o = dict(OPT); o["Mb"] = [0, 1] * 10
+    o = dict(OPT); o["Mb"] = [1, 0] * 10                 # the first stage cannot be blocked
     holder = SettingsHolder(o)
     h = C.c_void_p()
-    assert lib.eepacc_create(C.byref(h), C.byref(holder.pod), C.byref(veh), 0, 16) == -4
-    assert b"move blocking" in lib.eepacc_last_error()
+    assert lib.eepacc_create(C.byref(h), C.byref(holder.pod), C.byref(veh), 0, 16) == -1
+    assert b"Mb[0]" in lib.eepacc_last_error()

@@ -290,3 +290,35 @@ def test_reference_use_cases(case, torch_mod):
         assert int(st2.cpu().numpy().sum()) == 0
         for n, t in dict(xi_v=1e-6, xi_h=1e-6, xi_s=1e-6, xi_f=1e-6, a=1e-6, Fm=1e-2, Fb=1e-2).items():
             assert np.abs(o2[OUT[n]] - ref[:, OUT[n]]).max() < t, (case, "open loop", n)
+
+
+@pytest.mark.parametrize("tree", ["ABO", "ORIG"])
+def test_move_blocking(tree, torch_mod, lead_trace):
+    """Mb != 0 (ABO/Settings.m:243-250, rows CreateQP_AB.m:282-288: a_k = a_{k-1} on blocked stages),
+    done in the kernel as a change of variables; closed loop and per-step operator against the oracle,
+    which keeps the equality rows."""
+    from oracle import Oracle
+    OPT, V, _, _ = make_case(tree, 20)
+    OPT["Mb"] = np.array([0, 0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 1, 1, 0, 1], dtype=np.int32)
+    B, n_steps = 3, 80
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=2)
+    eng = _engine(OPT, V, 4)
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy(); st = status.cpu().numpy()
+    orc = Oracle(OPT, V)
+    tol = dict(s=1e-7, v=1e-8, a=1e-8, xi_v=1e-8, xi_h=1e-8, xi_s=1e-8, xi_f=1e-8, Fm=1e-4, Fb=1e-4)
+    for i in range(B):
+        ref, rst, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        assert rst.sum() == 0 and st[:, i].sum() == 0
+        for n, t in tol.items():
+            assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < t, (tree, i, n)
+    # predicted accelerations really are blocked: v_pred has equal increments inside a block
+    r = orc.ab_step(float(tr[40, OUT["s"], 0]), float(tr[40, OUT["v"], 0]), float(tr[40, OUT["a"], 0]) * 0 + (tr[40, OUT["v"], 0] - tr[39, OUT["v"], 0]) / 0.5,
+                    20.0, float(sc["s_tv"][40, 0]), float(sc["v_tv"][40, 0]), float((sc["v_tv"][40, 0] - sc["v_tv"][39, 0]) / 0.5))
+    out, sp, vp, st1 = eng.ab_step([r["out"][OUT["s"]]], [r["out"][OUT["v"]]], [(tr[40, OUT["v"], 0] - tr[39, OUT["v"], 0]) / 0.5], [20.0],
+                                   [sc["s_tv"][40, 0]], [sc["v_tv"][40, 0]], [(sc["v_tv"][40, 0] - sc["v_tv"][39, 0]) / 0.5])
+    vp = vp.cpu().numpy()[:, 0]
+    assert np.abs(vp - r["v_pred"]).max() < 1e-7
+    acc = np.diff(vp) / 0.5
+    blocked = np.nonzero(OPT["Mb"])[0]
+    assert np.abs(acc[blocked] - acc[blocked - 1]).max() < 1e-9
