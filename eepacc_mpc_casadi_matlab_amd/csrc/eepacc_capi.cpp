@@ -132,6 +132,12 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         for (int k = 0; k <= N; ++k) { C.mb_lead[k] = k; C.mb_end[k] = k; }
         C.mb_maxlen = 1;
     }
+    C.fb_row0[0] = 0;
+    for (int k = 0; k < N; ++k) {
+        C.mb_mask[k] = (S->Mb && S->Mb[k] == 1) ? 1 : 0;
+        C.fb_row0[k + 1] = C.fb_row0[k] + 26 + 2 * C.mb_mask[k];
+    }
+    C.mb_mask[N] = 0;
     C.w_FC = S->ab_fuel_term ? S->W_AB[0] : 0.0;
     C.w_a = S->W_AB[1]; C.w_j = S->W_AB[2]; C.w_v = S->W_AB[3]; C.w_h = S->W_AB[4]; C.w_s = S->W_AB[5]; C.w_f = S->W_AB[6];
     if (!(C.w_a > 0.0) || !(C.w_h > 0.0) || C.w_v < 0 || C.w_s < 0 || C.w_f < 0 || C.w_j < 0)
@@ -417,8 +423,7 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
 // FBMPC (ABO/RunOpt_FBMPC.m:161-331): build kernel -> dense QP operator -> extraction, per step.
 static int fb_prepare(eepacc_handle* h, int B) {
     const int N = h->cfg.N;
-    const size_t nV = 6 * (size_t)N, nC = 26 * (size_t)N + 2;
-    if (h->cfg.mb_any) return fail(EEPACC_ENOTSUP, "FBMPC: move blocking (Mb != 0, ABO/Settings.m:243-250) is not built yet");
+    const size_t nV = 6 * (size_t)N, nC = (size_t)h->cfg.fb_row0[N] + 2;
     if (nV > EEPACC_QP_MAX_NV || nC > EEPACC_QP_MAX_NC || eepacc_qp_dense_lds_bytes((int)nV, (int)nC) > 160 * 1024)
         return fail(EEPACC_ENOTSUP, "FBMPC: horizon too long for the dense QP operator");
     if (B <= h->fb_B) return EEPACC_OK;
@@ -460,7 +465,7 @@ static int fb_prepare(eepacc_handle* h, int B) {
 static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const double* v, const double* a_prev,
                        const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                        double* out, double* s_pred, double* v_pred, int32_t* status, hipStream_t stream) {
-    const int N = h->cfg.N, nV = 6 * N, nC = 26 * N + 2;
+    const int N = h->cfg.N, nV = 6 * N, nC = h->cfg.fb_row0[N] + 2;
     for (int b0 = 0; b0 < B; b0 += h->fb_chunk) {
         const int nb = (B - b0 < h->fb_chunk) ? B - b0 : h->fb_chunk;
         eepacc::eepacc_fb_args a;

@@ -62,6 +62,9 @@ struct DevCfg {
     double* pred;                 // device, [max_batch][2][64]: previous predicted s, v (paramEstSetting 2)
     // move blocking: stage k takes the acceleration of its block leader mb_lead[k]; a leader's block ends at mb_end[k]
     int32_t mb_lead[kMaxN + 1], mb_end[kMaxN + 1], mb_maxlen, mb_pad;
+    // FBMPC row layout: stage k owns rows fb_row0[k] .. fb_row0[k+1]-1 (26, or 28 with its two blocked-move rows)
+    int32_t fb_row0[kMaxN + 2];
+    int32_t mb_mask[kMaxN + 1];
 };
 
 }  // namespace eepacc

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(FT) k_fb_build(eepacc_fb_args a) {
     extern __shared__ __align__(16) double smem_d[];
     const DevCfg& C = *a.cfg;
     const int N = C.N, B = a.B, b = a.b0 + blockIdx.x, tid = threadIdx.x;
-    const int nV = 6 * N, nC = kRowsPerStage * N + 2;
+    const int nV = 6 * N, nC = C.fb_row0[N] + 2;
     StageData S;
     carve(S, smem_d, N);
     const double Ts = C.Tvec[0];
@@ -318,9 +318,20 @@ __global__ void __launch_bounds__(FT) k_fb_build(eepacc_fb_args a) {
     }
     // ---- A (column-major nC x nV), lba, uba
     for (int r = tid; r < nC; r += FT) {
-        const int k = r / kRowsPerStage < N ? r / kRowsPerStage : N;
-        const int t = r - k * kRowsPerStage;
-        RowDesc R = fb_row(C, S, k, t, s_0, v_0, a_minus1);
+        // stage of row r (stages own 26 rows, 28 with the two blocked-move rows CreateQP_FB.m:346-356 after the bounds)
+        int k = r / kRowsPerStage < N ? r / kRowsPerStage : N;
+        while (k > 0 && r < C.fb_row0[k]) --k;
+        while (k < N && r >= C.fb_row0[k + 1]) ++k;
+        int t = r - C.fb_row0[k];
+        RowDesc R;
+        if (k < N && C.mb_mask[k] && (t == 8 || t == 9)) {
+            R.as = R.av = R.aFm = R.aFb = R.aFmp = R.aFbp = R.sc = 0.0;
+            R.slack = -1; R.lb = 0.0; R.ub = 0.0;
+            if (t == 8) { R.aFmp = 1.0; R.aFm = -1.0; } else { R.aFbp = 1.0; R.aFb = -1.0; }
+        } else {
+            if (k < N && C.mb_mask[k] && t > 9) t -= 2;
+            R = fb_row(C, S, k, t, s_0, v_0, a_minus1);
+        }
         const double shift = R.as * S.ds[k] + R.av * S.dv[k];
         a.lba[lb_ * nC + r] = R.lb - shift;
         a.uba[lb_ * nC + r] = R.ub - shift;

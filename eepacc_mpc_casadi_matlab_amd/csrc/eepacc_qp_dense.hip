@@ -706,6 +706,12 @@ __device__ int gi_solve(const Prob& P, Ws& W, const Lds& S, double rho, int n_cr
         for (int c = threadIdx.x; c < P.m1; c += QT) {
             int row; double sgn, b;
             if (S.is_act[c] || !os_get(P, c, row, sgn, b)) continue;
+            if (S.is_act[c ^ 1]) {
+                // other side of a two-sided row is in the working set: with lb == ub (an equality, e.g.
+                // the blocked-move rows) this side holds by construction, whatever rounding says
+                const double lo = row >= 0 ? P.lba[row] : P.lbx[-row - 1], hi = row >= 0 ? P.uba[row] : P.ubx[-row - 1];
+                if (lo == hi) continue;
+            }
             double s = sgn * (row >= 0 ? S.ax[row] : S.x[-row - 1]) - b;
             double tol = 1e-11 * (1.0 + fabs(b));
             if (s < -tol && s < worst) { worst = s; p = c; }
@@ -953,6 +959,9 @@ __global__ void __launch_bounds__(QT, 2) k_qp_dense(eepacc_qp_args a) {     // t
                 TIC(t_k1);
                 int prc = kkt_solve(P, W, S, 0.0, P.g, S.act, q, S.xp, S.up, kkt);
                 TOC(t_k1, 7);
+#ifdef EEPACC_QP_DEBUG
+                if (threadIdx.x == 0 && it == 0) printf("qp %d round %d: q=%d prc=%d kkt=%g %g %g (nr=%d qg=%d)\n", b, it, q, prc, kkt[0], kkt[1], kkt[2], S.ired[2], S.ired[3]);
+#endif
                 if (prc == 0 && kkt[0] < 1e-9 && kkt[1] < 1e-9 && kkt[2] < 1e-9) {
                     for (int i = threadIdx.x; i < n; i += QT) S.x[i] = S.xp[i];
                     __syncthreads();

@@ -281,3 +281,20 @@ def test_fb_long_horizon_n60(torch_mod, lead_trace):
     ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][0]), 0.0, sc["s_tv"][:, 0].copy(), sc["v_tv"][:, 0].copy())
     np.testing.assert_array_equal(st[:, 0], rst)
     _compare_fb(tr[:, :, 0], ref, rst, scale=10.0)
+
+
+def test_fb_move_blocking(torch_mod, lead_trace):
+    """Mb != 0 for FBMPC: two equality rows per blocked stage (CreateQP_FB.m:346-356) in the dense QP."""
+    from oracle import Oracle
+    OPT, V, _, _ = make_case("ABO", 20)
+    OPT["Mb"] = np.array([0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 0, 1], dtype=np.int32)
+    B, n_steps = 2, 25
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=9)
+    eng = _engine(OPT, V, 2)
+    traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy(); st = status.cpu().numpy()
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        np.testing.assert_array_equal(st[:, i], rst)
+        _compare_fb(tr[:, :, i], ref, rst, scale=10.0)

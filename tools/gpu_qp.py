@@ -52,17 +52,22 @@ def run(eng, probs, tag, use_x0):
         P(f"  {tag}[{i}] status {status[i]} (oracle {p['status']}) iters {it[i]} (oracle {p['qp']['iterations']}) max|dx| {err:.3e} |x|max {np.abs(p['x']).max():.3e}")
     P(f"  {tag}: {dt*1e3:.1f} ms for {len(probs)} QPs")
 
-which = sys.argv[1] if len(sys.argv) > 1 else "all"
-OPT, V, s_tv, v_tv = make_case("ABO", 20)
-eng = Engine(OPT, V, device=0, max_batch=64)
-orc = Oracle(OPT, V)
-if which in ("all", "ab"):
-    G = load_golden("abo_abmpc")
-    probs = []
-    for k in (0, 1, 50, 120, 300, 500, 700):
-        r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, k), want_dense=True)
-        probs.append(r)
-    run(eng, probs, "AB20", False)
-if which in ("all", "fb"):
-    probs = fb_problems(orc, OPT, V, s_tv, v_tv, 10)
-    run(eng, probs, "FB20", True)
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    eng = Engine(OPT, V, device=0, max_batch=64)
+    orc = Oracle(OPT, V)
+    if which in ("all", "ab"):
+        G = load_golden("abo_abmpc")
+        probs = []
+        for k in (0, 1, 50, 120, 300, 500, 700):
+            r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, k), want_dense=True)
+            probs.append(r)
+        run(eng, probs, "AB20", False)
+    if which in ("all", "fb"):
+        probs = fb_problems(orc, OPT, V, s_tv, v_tv, 10)
+        run(eng, probs, "FB20", True)
+
+
+if __name__ == "__main__":
+    main()
