@@ -92,7 +92,11 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     const int N = S->N_hor;
     if (N < 2 || N > eepacc::kMaxN) return fail(EEPACC_EINVAL, "N_hor must be in [2, 63]");
     if (!S->Tvec) return fail(EEPACC_EINVAL, "Tvec is NULL");
-    if (S->solverToUse != 1) return fail(EEPACC_ENOTSUP, "only solverToUse == 1 (dense QP, ABO/Settings.m:114) is built");
+    // solverToUse 0 (sparse qpOASES) states the same QP as 1 (dense qpOASES) with the dynamics kept as
+    // equality rows (CreateQP_AB.m:227-246): same feasible set and objective, hence the same minimiser and
+    // the same kernels.  2 (HPIPM) is a different problem (hard bounds a in [-8, 8], :79-99).
+    if (S->solverToUse != 0 && S->solverToUse != 1)
+        return fail(EEPACC_ENOTSUP, "solverToUse == 2 (HPIPM formulation, ABO/Settings.m:114) is not built");
     if (S->paramEstSetting < 0 || S->paramEstSetting > 2) return fail(EEPACC_EINVAL, "paramEstSetting must be 0, 1 or 2");
     if (S->TVestSetting != 0 && S->TVestSetting != 1) return fail(EEPACC_EINVAL, "TVestSetting must be 0 or 1");
     if (S->n_speedLim < 1 || S->n_speedLim > eepacc::kMaxKnots || S->n_curv < 1 || S->n_curv > eepacc::kMaxKnots ||

@@ -74,7 +74,8 @@ typedef struct eepacc_settings {
     double  tConstACC_ego, tConstACC_tar;
     /* plant (ABO/Settings.m:111) */
     int32_t N_integratePlant;
-    /* solver selection (ABO/Settings.m:98,114); only dense qpOASES (1) is built */
+    /* solver selection (ABO/Settings.m:98,114): 0 and 1 (sparse / dense qpOASES) pose the same QP and
+     * are both accepted; 2 (HPIPM formulation with hard acceleration bounds) is not built */
     int32_t solverToUse;
     int32_t FBuseTaylor;
     /* power fits (ABO/Settings.m:229-238) */
