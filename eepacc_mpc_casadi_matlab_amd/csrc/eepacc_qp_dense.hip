@@ -46,6 +46,7 @@ struct Lds {
     int* jend;              // per row of A: one past its last non-zero column
     int* svar;              // per row of A: its column if it has exactly one non-zero, else -1
     int *kk_kind, *kk_vmap, *kk_free, *kk_gpos;   // index maps of kkt_solve
+    int* live;              // columns of A the violation scan has to read (ascending)
     unsigned char* is_act;
 };
 
@@ -159,6 +160,28 @@ __device__ void rows_times(const Prob& P, const double* x, double* ax, const int
             for (int u = 0; u < 8; ++u) s += v[u] * x[j + u];
         }
         for (; j < je; ++j) s += a[(size_t)j * ld] * x[j];
+        ax[i] = s;
+    }
+    __syncthreads();
+}
+
+// the same product restricted to the columns live[0..nlive): variables held at zero by an active bound
+// (most slack variables of an MPC QP) contribute nothing and their columns are not read
+__device__ void rows_times_live(const Prob& P, const double* x, double* ax, const int* jend, const int* live, int nlive) {
+    const size_t ld = (size_t)P.nC;
+    for (int i = threadIdx.x; i < P.nC; i += QT) {
+        double s = 0.0;
+        const double* a = P.A + i;
+        const int je = jend[i];
+        int t = 0;
+        for (; t + 8 <= nlive && live[t + 7] < je; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a[(size_t)live[t + u] * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u] * x[live[t + u]];
+        }
+        for (; t < nlive && live[t] < je; ++t) s += a[(size_t)live[t] * ld] * x[live[t]];
         ax[i] = s;
     }
     __syncthreads();
@@ -701,7 +724,23 @@ __device__ int gi_solve(const Prob& P, Ws& W, const Lds& S, double rho, int n_cr
     int refreshes = 0;
     for (;;) {
         TIC(t_scan);
-        rows_times(P, S.x, S.ax, S.jend);
+        // columns to read: all but the variables an active single-entry row or bound holds at exactly zero
+        for (int j = threadIdx.x; j < n; j += QT) S.hv[j] = 0.0;
+        __syncthreads();
+        for (int c = threadIdx.x; c < q; c += QT) {
+            int row; double sgn, b;
+            os_get(P, S.act[c], row, sgn, b);
+            const int var = row < 0 ? -row - 1 : S.svar[row];
+            if (var >= 0 && b == 0.0) S.hv[var] = 1.0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int nl = 0;
+            for (int j = 0; j < n; ++j) if (S.hv[j] == 0.0) S.live[nl++] = j;
+            S.ired[7] = nl;
+        }
+        __syncthreads();
+        rows_times_live(P, S.x, S.ax, S.jend, S.live, S.ired[7]);
         double worst = 0.0; int p = -1;
         for (int c = threadIdx.x; c < P.m1; c += QT) {
             int row; double sgn, b;
@@ -845,6 +884,7 @@ __device__ void carve(Lds& S, unsigned char* base, int n, int nC) {
     S.act = ip; ip += n + 2; S.crash = ip; ip += 2 * n; S.piv = ip; ip += n2; S.ired = ip; ip += 8;
     S.jend = ip; ip += nC; S.svar = ip; ip += nC;
     S.kk_kind = ip; ip += n + 2; S.kk_vmap = ip; ip += n; S.kk_free = ip; ip += n; S.kk_gpos = ip; ip += n + 2;
+    S.live = ip; ip += n;
     S.is_act = (unsigned char*)ip;
 }
 
@@ -1027,7 +1067,7 @@ size_t eepacc_qp_dense_ws_doubles(int nV) {
 size_t eepacc_qp_dense_lds_bytes(int nV, int nC) {
     const size_t n = (size_t)nV, n2 = 2 * n + 2;
     size_t dbl = 12 * n + 4 + 4 * n2 + (size_t)nC + 8;
-    size_t ints = (n + 2) + 2 * n + n2 + 8 + 2 * (size_t)nC + 4 * n + 4;
+    size_t ints = (n + 2) + 2 * n + n2 + 8 + 2 * (size_t)nC + 5 * n + 4;
     size_t bytes = dbl * 8 + ints * 4 + 2 * ((size_t)nC + n) + 16;
     return (bytes + 15) & ~(size_t)15;
 }
