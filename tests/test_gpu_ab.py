@@ -322,3 +322,22 @@ def test_move_blocking(tree, torch_mod, lead_trace):
     acc = np.diff(vp) / 0.5
     blocked = np.nonzero(OPT["Mb"])[0]
     assert np.abs(acc[blocked] - acc[blocked - 1]).max() < 1e-9
+
+
+@pytest.mark.parametrize("N", [2, 3, 32, 33, 63])
+def test_horizon_limits(N, torch_mod, lead_trace):
+    """Shortest horizons, both sides of the small / large kernel configuration (32 | 33) and the maximum."""
+    from oracle import Oracle
+    OPT, V, _, _ = make_case("ABO", N)
+    B, n_steps = 2, 12
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=4)
+    eng = _engine(OPT, V, 2)
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        ref, rst, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        assert rst.sum() == 0
+        for n in ("s", "v", "Fm", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
+            assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (N, i, n)

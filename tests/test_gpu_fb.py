@@ -298,3 +298,19 @@ def test_fb_move_blocking(torch_mod, lead_trace):
         ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
         np.testing.assert_array_equal(st[:, i], rst)
         _compare_fb(tr[:, :, i], ref, rst, scale=10.0)
+
+
+@pytest.mark.parametrize("N", [2, 5])
+def test_fb_short_horizons(N, torch_mod, lead_trace):
+    from oracle import Oracle
+    OPT, V, _, _ = make_case("ABO", N)
+    B, n_steps = 2, 8
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=4)
+    eng = _engine(OPT, V, 2)
+    traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy(); st = status.cpu().numpy()
+    orc = Oracle(OPT, V)
+    for i in range(B):
+        ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        np.testing.assert_array_equal(st[:, i], rst)
+        _compare_fb(tr[:, :, i], ref, rst, scale=10.0)
