@@ -61,6 +61,7 @@ struct eepacc_handle {
     double *fb_A22 = nullptr, *fb_D2 = nullptr;
     double *fb_sp = nullptr, *fb_vp = nullptr;   // [N+1][fb_B] predictions of the last step
     int32_t* fb_qpstat = nullptr;
+    int* fb_rhok = nullptr;                  // [fb_B] regularisation exponent found at the previous step
 };
 
 extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
@@ -263,6 +264,8 @@ static void fb_free(eepacc_handle* h) {
     for (double** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (h->fb_qpstat) (void)hipFree(h->fb_qpstat);
     h->fb_qpstat = nullptr;
+    if (h->fb_rhok) (void)hipFree(h->fb_rhok);
+    h->fb_rhok = nullptr;
     h->fb_B = 0; h->fb_chunk = 0;
 }
 
@@ -418,7 +421,7 @@ extern "C" int eepacc_qp_solve_batched(eepacc_handle* h, int B, int nV, int nC, 
     a.B = B; a.nV = nV; a.nC = nC; a.H = H; a.g = g; a.A = A; a.lba = lba; a.uba = uba; a.lbx = lbx; a.ubx = ubx;
     a.x0 = x0; a.x = x; a.cost = cost; a.status = status; a.iters = (B <= h->max_batch) ? h->d_iters : nullptr;
     a.ws = h->d_qp_ws; a.ws_stride = eepacc_qp_dense_ws_doubles(nV); a.rho_rel = 0.0; a.max_prox = 0;
-    a.counter = h->d_qp_counter;
+    a.counter = h->d_qp_counter; a.rho_k = nullptr;
     HIPCHK(hipMemsetAsync(h->d_qp_counter, 0, sizeof(int), (hipStream_t)stream));
     HIPCHK(eepacc_qp_dense_launch(a, grid, (hipStream_t)stream));
     return EEPACC_OK;
@@ -453,9 +456,11 @@ static int fb_prepare(eepacc_handle* h, int B) {
               hipMalloc(&h->fb_D2, nB * N * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->fb_sp, nB * (N + 1) * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->fb_vp, nB * (N + 1) * sizeof(double)) == hipSuccess &&
-              hipMalloc(&h->fb_qpstat, nB * sizeof(int32_t)) == hipSuccess;
+              hipMalloc(&h->fb_qpstat, nB * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc(&h->fb_rhok, nB * sizeof(int)) == hipSuccess;
     if (!ok) { fb_free(h); return fail(EEPACC_ENOMEM, "FBMPC: device allocation failed"); }
     HIPCHK(hipMemset(h->fb_x0, 0, nB * nV * sizeof(double)));
+    HIPCHK(hipMemset(h->fb_rhok, 0, nB * sizeof(int)));
     HIPCHK(hipMemset(h->fb_A22, 0, nB * N * sizeof(double)));
     HIPCHK(hipMemset(h->fb_D2, 0, nB * N * sizeof(double)));
     HIPCHK(hipMemset(h->fb_sp, 0, nB * (N + 1) * sizeof(double)));
@@ -488,7 +493,7 @@ static int fb_one_step(eepacc_handle* h, int B, int mode, const double* s, const
         q.x0 = h->fb_x0 + (size_t)b0 * nV; q.x = h->fb_x + (size_t)b0 * nV; q.cost = h->fb_cost + b0;
         q.status = h->fb_qpstat + b0; q.iters = (B <= h->max_batch) ? h->d_iters + b0 : nullptr;
         q.ws = h->d_qp_ws; q.ws_stride = eepacc_qp_dense_ws_doubles(nV); q.rho_rel = 0.0; q.max_prox = 0;
-        q.counter = h->d_qp_counter;
+        q.counter = h->d_qp_counter; q.rho_k = h->fb_rhok + b0;
         HIPCHK(hipMemsetAsync(h->d_qp_counter, 0, sizeof(int), stream));
         HIPCHK(eepacc_qp_dense_launch(q, grid, stream));
     }

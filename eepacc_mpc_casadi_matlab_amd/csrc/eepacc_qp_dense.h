@@ -12,6 +12,7 @@ struct eepacc_qp_args {
     double *x, *cost;
     int32_t *status, *iters;
     int* counter;          // device int, zeroed before the launch (work distribution)
+    int* rho_k;            // [B] in/out hint: exponent k of the regularisation found last time (may be NULL)
     double* ws;            // grid * ws_stride doubles
     size_t ws_stride;
     double rho_rel;        // <= 0: 1e-7

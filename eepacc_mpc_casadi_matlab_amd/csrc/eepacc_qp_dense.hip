@@ -930,15 +930,47 @@ __global__ void __launch_bounds__(QT, 2) k_qp_dense(eepacc_qp_args a) {     // t
         double* L = W.K;
         int chol_ok = 0;
         TIC(t_ch);
-        for (int tries = 0; tries < 60; ++tries) {
+        // rho = rho0 * 4^k with the smallest k for which H + rho I has a Cholesky factor.  The search
+        // starts from the hint k of the previous solve of this problem slot (the FB Hessian needs k = 10
+        // every step): try k-1, and if that fails take k, which costs two factorisations instead of k+1;
+        // positive definiteness is monotone in rho, so the result is the k of the search from zero.
+        const double rho0 = rho;
+        int kh = a.rho_k ? a.rho_k[b] : 0;
+        if (kh < 0 || kh > 59) kh = 0;
+        auto try_k = [&](int k) -> int {
+            const double r = rho0 * exp2(2.0 * k);
             for (int idx = threadIdx.x; idx < n * n; idx += QT) {
                 int i = idx / n, j = idx % n;
-                L[idx] = W.Hs[idx] + (i == j ? rho : 0.0);
+                L[idx] = W.Hs[idx] + (i == j ? r : 0.0);
             }
             __syncthreads();
-            if (chol_lower(L, n, S) == 0) { chol_ok = 1; break; }
+            const int ok = chol_lower(L, n, S) == 0;
             __syncthreads();
-            rho *= 4.0;
+            return ok;
+        };
+        int kfound = -1, last_ok = -1;
+        if (kh > 0) {
+            // walk down while the factor exists (it is kept for the smallest such k only if that was the last try)
+            int k = kh;
+            if (try_k(k - 1)) {
+                k = k - 1;
+                while (k > 0 && try_k(k - 1)) --k;
+                kfound = k;                      // k-1 failed (or k == 0): L holds garbage of the failed try unless k == 0
+                last_ok = (k == 0) ? 0 : -1;
+            } else {
+                while (k < 60 && !try_k(k)) ++k;
+                if (k < 60) { kfound = k; last_ok = k; }
+            }
+        } else {
+            int k = 0;
+            while (k < 60 && !try_k(k)) ++k;
+            if (k < 60) { kfound = k; last_ok = k; }
+        }
+        if (kfound >= 0 && last_ok != kfound) try_k(kfound);          // re-factor: the last attempt was a failing one
+        chol_ok = kfound >= 0;
+        if (chol_ok) {
+            rho = rho0 * exp2(2.0 * kfound);
+            if (a.rho_k && threadIdx.x == 0) a.rho_k[b] = kfound;
         }
         int status = 1, tot_iters = 0, q = 0;
         if (chol_ok) {
