@@ -195,7 +195,7 @@ def main():
                        "bad_exits": int(kpi[0].item())},
             "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 1, 20) if fb else cpu_baseline(OPT, V, sc)
             res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(res))
