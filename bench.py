@@ -23,13 +23,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def cpu_baseline(OPT, V, sc, kind="ab", n_inst=2, n_steps=60):
+def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
     """The oracle (literal dense condensing + dense active set) on the host on a bounded sample of
     the same workload: (i) one thread, (ii) one instance per thread on every host core
     (the C oracle is re-entrant and ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import Oracle
     orc = Oracle(OPT, V)
+    n_steps = min(n_steps, sc["s_tv"].shape[0])
 
     def one(i):
         orc.run(kind, n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:n_steps, i].copy(), sc["v_tv"][:n_steps, i].copy())
@@ -43,7 +44,7 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=2, n_steps=60):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))        # a one-GPU box offers 16 host cores to the job
-    n_all = min(2 * cores, sc["v0"].shape[0])
+    n_all = min(4 * cores, sc["v0"].shape[0])
     t1 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         done_all = sum(ex.map(one, range(n_all)))
@@ -196,7 +197,7 @@ def main():
             "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 1, 20) if fb else cpu_baseline(OPT, V, sc)
+            res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 2, 8) if fb else cpu_baseline(OPT, V, sc)      # ~10-20 s of host work
             res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(res))
     if world > 1:
