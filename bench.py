@@ -6,7 +6,7 @@ One "step" = one receding-horizon step (estimate -> condense -> QP -> allocate -
 region runs K consecutive closed-loop steps (after W warm-up steps of the same simulation) with
 all inputs resident in HBM; value = instances * K / time over all ranks.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 200
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -85,7 +85,9 @@ def main():
     dev = local_rank
     fb = args.workload == "fbmpc"
     K = args.steps if args.steps is not None else (6 if fb else 200)
-    W = args.warmup if args.warmup is not None else (2 if fb else 20)
+    # default warm-up = one launch of the same size as the timed one, so that the per-kernel average
+    # of a rocprofv3 --stats run of the default command is the timed launch's duration
+    W = args.warmup if args.warmup is not None else (2 if fb else 200)
     N, B = args.horizon, args.batch
     OPT, V, _, _ = make_case("ABO", N)
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
