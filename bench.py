@@ -192,7 +192,8 @@ def main():
                          "definition": "R-materialised (SURVEY.md 8d): bytes the reference's dense-QP API moves per QP step "
                                        "(%d B at N=%d) x QP steps per launch / mean launch time (HIP events)%s"
                                        % (bytes_mat, N, "; FBMPC materialises exactly this QP in HBM for the dense QP operator" if fb else
-                                          "; the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it" % bytes_fused),
+                                          "; the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it and a fraction above 1 "
+                                          "just says: faster than any implementation that moves the materialised QP through HBM" % bytes_fused),
                          "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3},
             "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (1 if fb else K / launches),
                        "bad_exits": int(kpi[0].item())},
