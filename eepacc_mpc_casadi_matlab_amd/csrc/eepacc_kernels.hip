@@ -38,7 +38,7 @@ constexpr int kChunkStepsDefault = nomb::kChunkStepsDefault;
 
 #ifdef EEPACC_AB_TIMING
 extern "C" int eepacc_debug_ab_prof(unsigned long long* out, int reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nomb::g_ab_prof), sizeof(z)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(nomb::g_ab_prof), z, sizeof(z)) != hipSuccess) return -1;
     return 0;

@@ -16,8 +16,9 @@ lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
 sc = make_s2(B, n, lead["V_TO_2Hz"])
 eng = Engine(OPT, V, device=0, max_batch=B)
 lib = load_library()
-names = ["rebuild+factor", "multipliers", "refine", "warm repair", "find violation", "step/apply", "setup", "outputs", "solve total", " he_sync", " list", " S build", " inversion", "-"]
-prof = (C.c_ulonglong * 16)()
+names = ["rebuild+factor", "multipliers", "refine", "warm repair", "find violation", "step/apply", "setup", "outputs", "solve total", " he_sync", " list", " S build", " inversion", "passes"]
+why_names = ["first pass", "warm repair", "EV_CAP", "COMPL/CAPIN/DROPH", "bound add", "duplicate", "cap reset", "cold", "add with m=0"]
+prof = (C.c_ulonglong * 24)()
 mvals = []
 stv = torch.as_tensor(sc["s_tv"], device="cuda"); vtv = torch.as_tensor(sc["v_tv"], device="cuda")
 eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], stv[:20], vtv[:20]); torch.cuda.synchronize()
@@ -30,4 +31,7 @@ tot = sum(prof[i] for i in (6, 7, 8))
 P(f"200 steps x {B}: {dt*1e3:.1f} ms (instrumented)")
 for i, nm in enumerate(names):
     P(f"  {nm:16s} {prof[i] / 100.0 / (B * 200):8.3f} us/step  {100.0 * prof[i] / tot:5.1f} %")
+P("passes/step", prof[13] / (B * 200.0))
+for i, nm in enumerate(why_names):
+    P(f"  full rebuilds/step because {nm:20s} {prof[14 + i] / (B * 200.0):.3f}")
 P("iterations/step", eng.last_iterations(B).mean() / 200)
