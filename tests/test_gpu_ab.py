@@ -313,10 +313,11 @@ def test_move_blocking(tree, torch_mod, lead_trace):
         for n, t in tol.items():
             assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < t, (tree, i, n)
     # predicted accelerations really are blocked: v_pred has equal increments inside a block
-    r = orc.ab_step(float(tr[40, OUT["s"], 0]), float(tr[40, OUT["v"], 0]), float(tr[40, OUT["a"], 0]) * 0 + (tr[40, OUT["v"], 0] - tr[39, OUT["v"], 0]) / 0.5,
-                    20.0, float(sc["s_tv"][40, 0]), float(sc["v_tv"][40, 0]), float((sc["v_tv"][40, 0] - sc["v_tv"][39, 0]) / 0.5))
-    out, sp, vp, st1 = eng.ab_step([r["out"][OUT["s"]]], [r["out"][OUT["v"]]], [(tr[40, OUT["v"], 0] - tr[39, OUT["v"], 0]) / 0.5], [20.0],
-                                   [sc["s_tv"][40, 0]], [sc["v_tv"][40, 0]], [(sc["v_tv"][40, 0] - sc["v_tv"][39, 0]) / 0.5])
+    a_prev = float((tr[40, OUT["v"], 0] - tr[39, OUT["v"], 0]) / 0.5)
+    a_tv = float((sc["v_tv"][40, 0] - sc["v_tv"][39, 0]) / 0.5)
+    inp = (float(tr[40, OUT["s"], 0]), float(tr[40, OUT["v"], 0]), a_prev, 20.0, float(sc["s_tv"][40, 0]), float(sc["v_tv"][40, 0]), a_tv)
+    r = orc.ab_step(*inp)
+    out, sp, vp, st1 = eng.ab_step(*[[x] for x in inp])
     vp = vp.cpu().numpy()[:, 0]
     assert np.abs(vp - r["v_pred"]).max() < 1e-7
     acc = np.diff(vp) / 0.5
