@@ -195,6 +195,15 @@ def main():
                                           "; the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it and a fraction above 1 "
                                           "just says: faster than any implementation that moves the materialised QP through HBM" % bytes_fused),
                          "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3},
+            # the other two yardsticks of SURVEY.md 8d, for the record: compulsory ("R-fused") HBM bytes, and
+            # the algorithmic flops of the literal dense path (F_cond + n_iter F_iter, n_a ~ 4N) against the
+            # vector-fp64 peak; neither binds the fused kernel
+            "alt_rooflines": None if fb else {
+                "r_fused_hbm": {"bytes_per_step": bytes_fused, "achieved_GBps": bytes_fused * qp_per_launch / launch_s / 1e9,
+                                "frac": bytes_fused * qp_per_launch / launch_s / 1e9 / 8000.0},
+                "dense_path_fp64": (lambda it: {"flops_per_step": 2 * N ** 3 + 2 * nC * N + it * (4 * (4 * N) ** 2 + 2 * nC * N),
+                                                "achieved_TFLOPs": (2 * N ** 3 + 2 * nC * N + it * (4 * (4 * N) ** 2 + 2 * nC * N)) * qp_per_launch / launch_s / 1e12,
+                                                "peak_TFLOPs": 78.6})(float(iters.mean()) / (K / launches))},
             "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (1 if fb else K / launches),
                        "bad_exits": int(kpi[0].item())},
             "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
