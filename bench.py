@@ -78,11 +78,17 @@ def main():
 
     from eepacc_mpc_casadi_matlab_amd.distributed import rank_world, shard_range, reduce_kpis, max_over_ranks
     rank, world, local_rank = rank_world()
+    # one rank per GPU over RCCL ("nccl"); EEPACC_DIST_BACKEND=gloo rehearses the multi-rank flow on fewer
+    # GPUs than ranks (ranks then share devices round-robin and the KPI vector is reduced on the host)
+    backend = os.environ.get("EEPACC_DIST_BACKEND", "nccl")
+    dev = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     fb = args.workload == "fbmpc"
     K = args.steps if args.steps is not None else (6 if fb else 200)
     # default warm-up = one launch of the same size as the timed one, so that the per-kernel average
@@ -119,7 +125,7 @@ def main():
         tw, sw = buf[0][:1].zero_(), buf[1][:1].zero_()
     bad_w = torch.zeros((), dtype=torch.int64, device=d)
     bad_w += sw.sum()                  # the same in-place int64 add the timed loop issues (a lazily loaded kernel costs ~10 ms)
-    kw = reduce_kpis(kpis(tw, bad_w), world)
+    kw = reduce_kpis(kpis(tw, bad_w) if backend == "nccl" else kpis(tw, bad_w).cpu(), world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,14 +146,14 @@ def main():
         k = hi
     ev1.record(stream)
     # KPI reduction (the only collective of the job): bad exits, distance, sum a^2
-    kpi = reduce_kpis(kpis(traj, bad), world)
+    kpi = reduce_kpis(kpis(traj, bad) if backend == "nccl" else kpis(traj, bad).cpu(), world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)
-    dt = max_over_ranks(dt, world, d)
+    dt = max_over_ranks(dt, world, d if backend == "nccl" else None)
     iters = eng.last_iterations(B)
 
     if rank == 0:
