@@ -21,7 +21,7 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double*
 hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
-                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int num_cus,
+                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int* err_word, int num_cus,
                             hipStream_t stream);
 hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
                               double* P, double* E, hipStream_t stream);
@@ -46,6 +46,7 @@ struct eepacc_handle {
     double* d_carry = nullptr;               // [6][B] closed-loop carry (see k_run_abmpc)
     int* d_counter = nullptr;                // work counter of the closed-loop kernel
     int* d_done = nullptr;                   // [max_batch] chunks finished per instance
+    int* d_err = nullptr;                    // sticky device error word (bit 0: a closed-loop hand-off timed out)
     int num_cus = 256;
     int last_B = 0;
     int k_done = 0;                          // closed-loop steps already run since the last reset
@@ -228,7 +229,9 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     if (ndev < 1) return fail(EEPACC_EDEVICE, "no HIP device: libeepacc has no CPU path");
     if (device < 0 || device >= ndev) return fail(EEPACC_EINVAL, "device ordinal out of range");
     HIPCHK(hipSetDevice(device));
-    eepacc_handle* h = new eepacc_handle();
+    // the handle is destroyed (and everything allocated so far freed) if any later step fails
+    struct Guard { eepacc_handle* h; ~Guard() { if (h) eepacc_destroy(h); } } guard{new eepacc_handle()};
+    eepacc_handle* h = guard.h;
     h->device = device; h->max_batch = max_batch;
     HIPCHK(hipMalloc(&h->d_Hinv, Hinv.size() * sizeof(double)));
     HIPCHK(hipMemcpy(h->d_Hinv, Hinv.data(), Hinv.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -247,6 +250,8 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMemset(h->d_carry, 0, (size_t)max_batch * 6 * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(int)));
     HIPCHK(hipMalloc(&h->d_done, sizeof(int) * (size_t)max_batch));
+    HIPCHK(hipMalloc(&h->d_err, sizeof(int)));
+    HIPCHK(hipMemset(h->d_err, 0, sizeof(int)));
     HIPCHK(hipMalloc(&h->d_qp_counter, sizeof(int)));
     {
         hipDeviceProp_t prop;
@@ -254,6 +259,7 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     HIPCHK(eepacc::set_max_smem());
+    guard.h = nullptr;
     *out = h;
     return EEPACC_OK;
 }
@@ -280,6 +286,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_carry) (void)hipFree(h->d_carry);
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_done) (void)hipFree(h->d_done);
+    if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_qp_ws) (void)hipFree(h->d_qp_ws);
     if (h->d_qp_counter) (void)hipFree(h->d_qp_counter);
     fb_free(h);
@@ -291,6 +298,7 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemset(h->d_codes, 0, (size_t)h->max_batch * 64 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_pred, 0, (size_t)h->max_batch * 128 * sizeof(double)));
+    HIPCHK(hipMemset(h->d_err, 0, sizeof(int)));
     h->k_done = 0; h->carry_B = 0;
     h->fb_k_done = 0;
     if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));
@@ -329,41 +337,10 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");
     h->last_B = B;
     HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, h->cfg.mb_any != 0, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
-                                    h->d_carry, h->d_codes, traj, status, h->d_iters, h->d_counter, h->d_done, h->num_cus,
+                                    h->d_carry, h->d_codes, traj, status, h->d_iters, h->d_counter, h->d_done, h->d_err, h->num_cus,
                                     (hipStream_t)stream));
     h->k_done += n_steps; h->carry_B = B;
     return EEPACC_OK;
-}
-
-extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
-                                     const double* a_minus1, const double* s_tv, const double* v_tv,
-                                     double* traj, int32_t* status) {
-    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
-    if (B < 1 || B > h->max_batch || n_steps < 1) return fail(EEPACC_EINVAL, "bad B / n_steps");
-    HIPCHK(hipSetDevice(h->device));
-    double *d_in = nullptr, *d_tv = nullptr, *d_traj = nullptr;
-    int32_t* d_status = nullptr;
-    int rc0 = EEPACC_OK;
-    const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
-    HIPCHK(hipMalloc(&d_in, 3 * nB * sizeof(double)));
-    HIPCHK(hipMalloc(&d_tv, 2 * nT * sizeof(double)));
-    HIPCHK(hipMalloc(&d_traj, nT * EEPACC_OUT_N * sizeof(double)));
-    HIPCHK(hipMalloc(&d_status, nT * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(d_in, s0, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_in + nB, v0, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
-    rc0 = eepacc_reset(h);
-    if (rc0 != EEPACC_OK) return rc0;
-    int rc = eepacc_run_abmpc(h, B, n_steps, d_in, d_in + nB, d_in + 2 * nB, d_tv, d_tv + nT, d_traj, d_status, nullptr);
-    if (rc == EEPACC_OK) {
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(traj, d_traj, nT * EEPACC_OUT_N * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(status, d_status, nT * sizeof(int32_t), hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_in); (void)hipFree(d_tv); (void)hipFree(d_traj); (void)hipFree(d_status);
-    return rc;
 }
 
 extern "C" int eepacc_postprocess(eepacc_handle* h, int B, int n_steps, const double* traj, double* rpm,
@@ -382,6 +359,23 @@ extern "C" int eepacc_last_iterations(eepacc_handle* h, int B, int32_t* iters_ho
     HIPCHK(hipMemcpy(iters_host, h->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
     return EEPACC_OK;
 }
+
+extern "C" int eepacc_synchronize(eepacc_handle* h, void* stream) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (err != 0)
+        return fail(EEPACC_EDEVICE, "closed-loop kernel: a work unit waited for its predecessor beyond the spin limit; "
+                                    "the affected steps carry status 3 and the results of this launch are invalid");
+    return EEPACC_OK;
+}
+
+#ifndef EEPACC_BUILD_FLAGS
+#define EEPACC_BUILD_FLAGS ""
+#endif
+extern "C" const char* eepacc_build_flags(void) { return EEPACC_BUILD_FLAGS; }
 
 // B3 -- dense QP operator (ABO/RunOpt_ABMPC.m:252)
 // persistent workgroups of the dense QP kernel per compute unit (EEPACC_QP_WGS_PER_CU overrides)
@@ -523,7 +517,7 @@ extern "C" int eepacc_fb_step(eepacc_handle* h, int B, const double* s, const do
     if (!h) return fail(EEPACC_EINVAL, "NULL handle");
     if (B < 0 || B > h->max_batch) return fail(EEPACC_EINVAL, "B exceeds max_batch of the handle");
     if (B == 0) return EEPACC_OK;
-    if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out)
+    if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out || !status)
         return fail(EEPACC_EINVAL, "eepacc_fb_step: NULL buffer");
     HIPCHK(hipSetDevice(h->device));
     int rc = fb_prepare(h, B);
@@ -553,32 +547,56 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
     return EEPACC_OK;
 }
 
+// Host-pointer wrappers (what the MEX gateways mex/RunOpt_*MPC.c call): copy in, reset, run, wait, copy out.
+namespace {
+struct DevBufs {       // device scratch of the wrappers, freed on every return path
+    double *in = nullptr, *tv = nullptr, *traj = nullptr;
+    int32_t* status = nullptr;
+    ~DevBufs() {
+        if (in) (void)hipFree(in);
+        if (tv) (void)hipFree(tv);
+        if (traj) (void)hipFree(traj);
+        if (status) (void)hipFree(status);
+    }
+};
+}  // namespace
+
+static int run_host(eepacc_handle* h, bool fb, int B, int n_steps, const double* s0, const double* v0,
+                    const double* a_minus1, const double* s_tv, const double* v_tv, double* traj, int32_t* status) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (B < 1 || B > h->max_batch || n_steps < 1) return fail(EEPACC_EINVAL, "bad B / n_steps");
+    if (!s0 || !v0 || !a_minus1 || !s_tv || !v_tv || !traj || !status) return fail(EEPACC_EINVAL, "NULL buffer");
+    HIPCHK(hipSetDevice(h->device));
+    DevBufs d;
+    const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
+    HIPCHK(hipMalloc(&d.in, 3 * nB * sizeof(double)));
+    HIPCHK(hipMalloc(&d.tv, 2 * nT * sizeof(double)));
+    HIPCHK(hipMalloc(&d.traj, nT * EEPACC_OUT_N * sizeof(double)));
+    HIPCHK(hipMalloc(&d.status, nT * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(d.in, s0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.in + nB, v0, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
+    int rc = eepacc_reset(h);
+    if (rc != EEPACC_OK) return rc;
+    rc = fb ? eepacc_run_fbmpc(h, B, n_steps, d.in, d.in + nB, d.in + 2 * nB, d.tv, d.tv + nT, d.traj, d.status, nullptr)
+            : eepacc_run_abmpc(h, B, n_steps, d.in, d.in + nB, d.in + 2 * nB, d.tv, d.tv + nT, d.traj, d.status, nullptr);
+    if (rc != EEPACC_OK) return rc;
+    rc = eepacc_synchronize(h, nullptr);
+    HIPCHK(hipMemcpy(traj, d.traj, nT * EEPACC_OUT_N * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, d.status, nT * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return rc;
+}
+
+extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                     const double* a_minus1, const double* s_tv, const double* v_tv,
+                                     double* traj, int32_t* status) {
+    return run_host(h, false, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status);
+}
+
 extern "C" int eepacc_run_fbmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
                                      const double* a_minus1, const double* s_tv, const double* v_tv,
                                      double* traj, int32_t* status) {
-    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
-    if (B < 1 || B > h->max_batch || n_steps < 1) return fail(EEPACC_EINVAL, "bad B / n_steps");
-    HIPCHK(hipSetDevice(h->device));
-    double *d_in = nullptr, *d_tv = nullptr, *d_traj = nullptr;
-    int32_t* d_status = nullptr;
-    const size_t nB = (size_t)B, nT = (size_t)n_steps * B;
-    HIPCHK(hipMalloc(&d_in, 3 * nB * sizeof(double)));
-    HIPCHK(hipMalloc(&d_tv, 2 * nT * sizeof(double)));
-    HIPCHK(hipMalloc(&d_traj, nT * EEPACC_OUT_N * sizeof(double)));
-    HIPCHK(hipMalloc(&d_status, nT * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(d_in, s0, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_in + nB, v0, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_in + 2 * nB, a_minus1, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_tv, s_tv, nT * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_tv + nT, v_tv, nT * sizeof(double), hipMemcpyHostToDevice));
-    int rc = eepacc_reset(h);
-    if (rc == EEPACC_OK)
-        rc = eepacc_run_fbmpc(h, B, n_steps, d_in, d_in + nB, d_in + 2 * nB, d_tv, d_tv + nT, d_traj, d_status, nullptr);
-    if (rc == EEPACC_OK) {
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(traj, d_traj, nT * EEPACC_OUT_N * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(status, d_status, nT * sizeof(int32_t), hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_in); (void)hipFree(d_tv); (void)hipFree(d_traj); (void)hipFree(d_status);
-    return rc;
+    return run_host(h, true, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status);
 }

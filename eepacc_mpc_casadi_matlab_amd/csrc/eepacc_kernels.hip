@@ -69,7 +69,7 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double*
 hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
-                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int num_cus,
+                            int32_t* status, int32_t* iters_total, int* work_counter, int* done, int* err_word, int num_cus,
                             hipStream_t stream) {
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
@@ -84,16 +84,19 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start
         const char* ev = getenv("EEPACC_CHUNK");
         kChunkSteps = (ev && atoi(ev) > 0) ? atoi(ev) : kChunkStepsDefault;
     }
+    // bound of the inter-unit spin wait (a debug hook lowers it to exercise the failure path)
+    int spin_limit = 1 << 26;
+    if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) spin_limit = atoi(ev);
     const int n_units = ((n_steps + kChunkSteps - 1) / kChunkSteps) * B;
     // one chip-filling wave of blocks: LDS admits 8 (small) / 2 (large) waves per CU
     if (N > kNSSmall) {
         int grid = num_cus * 1, need = (n_units + 1) / 2;
         if (grid > need) grid = need;
-        EEPACC_LAUNCH(k_run_abmpc, kMMaxLarge, kNSLarge, 2, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps);
+        EEPACC_LAUNCH(k_run_abmpc, kMMaxLarge, kNSLarge, 2, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
     } else {
         int grid = num_cus * 2, need = (n_units + 3) / 4;
         if (grid > need) grid = need;
-        EEPACC_LAUNCH(k_run_abmpc, kMMaxSmall, kNSSmall, 4, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps);
+        EEPACC_LAUNCH(k_run_abmpc, kMMaxSmall, kNSSmall, 4, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
     }
     return hipGetLastError();
 }

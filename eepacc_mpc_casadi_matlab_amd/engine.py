@@ -13,7 +13,7 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
-from ._abi import SettingsHolder, SettingsPOD, Vehicle, make_vehicle, OUT, OUT_N, OUT_FIELDS, c_double_p
+from ._abi import SettingsHolder, SettingsPOD, Vehicle, make_vehicle, OUT, OUT_N, OUT_FIELDS, c_double_p, as_dptr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libeepacc.so")
@@ -53,6 +53,8 @@ def load_library() -> C.CDLL:
     lib.eepacc_run_fbmpc.argtypes = [vp, C.c_int, C.c_int] + [dp] * 5 + [dp, dp, vp]
     lib.eepacc_run_fbmpc_host.argtypes = [vp, C.c_int, C.c_int] + [c_double_p] * 5 + [c_double_p, ip]
     lib.eepacc_qp_solve_batched.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [dp] * 8 + [dp, dp, dp, vp]
+    lib.eepacc_synchronize.argtypes = [vp, vp]
+    lib.eepacc_build_flags.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -60,7 +62,7 @@ def load_library() -> C.CDLL:
 ABI_SYMBOLS = ["eepacc_last_error", "eepacc_version", "eepacc_sizeof_settings", "eepacc_sizeof_vehicle", "eepacc_create", "eepacc_destroy", "eepacc_reset",
                "eepacc_ab_step", "eepacc_run_abmpc", "eepacc_fb_step", "eepacc_run_fbmpc",
                "eepacc_run_abmpc_host", "eepacc_run_fbmpc_host", "eepacc_postprocess",
-               "eepacc_last_iterations", "eepacc_qp_solve_batched"]
+               "eepacc_last_iterations", "eepacc_qp_solve_batched", "eepacc_synchronize", "eepacc_build_flags"]
 
 
 def _check(rc: int):
@@ -209,6 +211,27 @@ class Engine:
                                                 ptr(lba), ptr(uba), ptr(lbx), ptr(ubx), ptr(x0), x.data_ptr(),
                                                 cost.data_ptr(), status.data_ptr(), self._stream()))
         return x, cost, status
+
+    def synchronize(self):
+        """Wait for the engine's stream; raises if a closed-loop launch flagged a device-side failure."""
+        _check(self.lib.eepacc_synchronize(self.h, self._stream()))
+
+    def _run_host(self, fn, s0, v0, a_minus1, s_tv, v_tv):
+        s_tv = np.ascontiguousarray(s_tv, dtype=np.float64); v_tv = np.ascontiguousarray(v_tv, dtype=np.float64)
+        n_steps, B = s_tv.shape
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)) for x in (s0, v0, a_minus1)]
+        assert all(x.size == B for x in ins)
+        traj = np.empty((n_steps, OUT_N, B)); status = np.empty((n_steps, B), dtype=np.int32)
+        _check(fn(self.h, B, n_steps, *[as_dptr(x) for x in ins], as_dptr(s_tv), as_dptr(v_tv), as_dptr(traj),
+                  status.ctypes.data_as(C.POINTER(C.c_int32))))
+        return traj, status
+
+    def run_abmpc_host(self, s0, v0, a_minus1, s_tv, v_tv):
+        """eepacc_run_abmpc_host: host (numpy) buffers in and out -- the entry a MEX gateway calls."""
+        return self._run_host(self.lib.eepacc_run_abmpc_host, s0, v0, a_minus1, s_tv, v_tv)
+
+    def run_fbmpc_host(self, s0, v0, a_minus1, s_tv, v_tv):
+        return self._run_host(self.lib.eepacc_run_fbmpc_host, s0, v0, a_minus1, s_tv, v_tv)
 
     def last_iterations(self, B):
         it = np.zeros(B, dtype=np.int32)

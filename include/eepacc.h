@@ -17,7 +17,13 @@
  *     ABO/RunOpt_ABMPC.m:121,255) the iterate is still applied and status[i] = 1 mirrors
  *     optSol.exitMessage(k).
  *   - a handle owns its device workspaces and per-instance warm-start state; it is
- *     thread-compatible (one handle per host thread / stream), not thread-safe.
+ *     thread-compatible (one handle per host thread / stream), not thread-safe, and admits ONE
+ *     launch in flight at a time: the closed-loop kernels hand their loop state from work unit to
+ *     work unit through buffers of the handle, so a second eepacc_run_* on another stream of the
+ *     same handle must wait for the first (use one handle per concurrent stream).
+ *   - status values: 0 solved, 1 QP not converged / infeasible (the reference's exitMessage),
+ *     3 the step was not computed because a device-side wait timed out (then eepacc_synchronize
+ *     returns EEPACC_EDEVICE; never expected in normal operation).
  */
 #ifndef EEPACC_H
 #define EEPACC_H
@@ -196,6 +202,15 @@ int  eepacc_postprocess(eepacc_handle* h, int B, int n_steps, const double* traj
 
 /* Solver statistics of the last launch, device [B]: active-set iterations used. */
 int  eepacc_last_iterations(eepacc_handle* h, int B, int32_t* iters_host);
+
+/* Wait for the work queued on `stream` and report the handle's sticky device error word:
+ * EEPACC_EDEVICE if a closed-loop launch since the last eepacc_reset could not hand its loop state
+ * on (affected steps carry status 3), EEPACC_OK otherwise.  The *_host wrappers call it themselves. */
+int  eepacc_synchronize(eepacc_handle* h, void* stream);
+
+/* Flag string the library was compiled with ("" for a release build; instrumented builds such as
+ * -DEEPACC_AB_TIMING change the meaning of the iteration / status outputs). */
+const char* eepacc_build_flags(void);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,13 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), name
 
 
+def test_release_build(lib):
+    """Instrumented builds (-DEEPACC_AB_TIMING, -DEEPACC_DEBUG_STATUS ...) change the meaning of the status and
+    iteration outputs: tests and bench must run against a library built without extra flags."""
+    assert lib.eepacc_build_flags() == b"", lib.eepacc_build_flags()
+    assert eb.built_flags() == ""
+
+
 def test_struct_layouts_match(lib):
     assert lib.eepacc_sizeof_settings() == C.sizeof(SettingsPOD)
     assert lib.eepacc_sizeof_vehicle() == C.sizeof(Vehicle)

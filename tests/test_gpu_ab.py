@@ -266,19 +266,29 @@ def test_reference_use_cases(case, torch_mod):
     traj, status = eng.run_abmpc(np.full(B, OPT["s_init"]), np.full(B, OPT["v_init"]), np.full(B, OPT["a_minus1"]),
                                  np.repeat(s_tv[:, None], B, 1), np.repeat(v_tv[:, None], B, 1))
     tr = traj.cpu().numpy(); st = status.cpu().numpy()
+    eng.synchronize()
+    # run-to-run and instance-to-instance bit reproducibility first (a tolerance failure below is then a
+    # deterministic distance to the oracle, not a race): same engine, second launch
+    traj2, status2 = eng.run_abmpc(np.full(B, OPT["s_init"]), np.full(B, OPT["v_init"]), np.full(B, OPT["a_minus1"]),
+                                   np.repeat(s_tv[:, None], B, 1), np.repeat(v_tv[:, None], B, 1))
+    assert np.array_equal(traj2.cpu().numpy(), tr) and np.array_equal(status2.cpu().numpy(), st), case
+    assert np.abs(tr[:, :, 0] - tr[:, :, 1]).max() == 0.0
     ref, rst, _ = Oracle(OPT, V).run("ab", n_steps, OPT["s_init"], OPT["v_init"], OPT["a_minus1"], s_tv.copy(), v_tv.copy())
     assert np.array_equal(rst != 0, st[:, 0] != 0)
     assert rst.sum() == 0
     assert np.isfinite(tr).all()
-    # ORIG weights span 1e2 .. 1e7 (w_f): crawling up to a stop line the two solvers agree to 4e-8 m/s
-    tol = dict(s=1e-6, v=1e-7, a=1e-7, xi_v=1e-7, xi_h=1e-7, xi_s=1e-7, xi_f=1e-7, Fm=1e-3, Fb=1e-3)
+    # ORIG weights span 1e2 .. 1e7 (w_f): the two solvers stop at KKT points 1e-8 apart and the closed loop
+    # amplifies that while crawling towards a stop line.  Largest distances measured on MI355X over the use
+    # cases (tools/gpu_uc_margins.py -> profiles/r02_uc_margins.txt): case 5 s 8.4e-8, v 4.3e-8, a 8.5e-8,
+    # Fm 1.3e-4; case 12 v 1.6e-8.  The tolerances keep a factor >= 3.5 over those (the round-1 values sat on a
+    # 1.06e-7 reading of case 12 that no release build reproduces; tests/test_abi.py now pins the build flags).
+    tol = dict(s=1e-6, v=3e-7, a=3e-7, xi_v=3e-7, xi_h=3e-7, xi_s=3e-7, xi_f=3e-7, Fm=1e-3, Fb=1e-3)
     # the long route (11) is compared in closed loop up to the approach of the stop line at 4000 m,
     # where a 1e-8 difference between the solvers is amplified by the loop (2 m after 800 more steps);
     # beyond it every step is checked as an open-loop QP at the oracle's states instead
     n_cl = 560 if case == 11 else n_steps
     for n, t in tol.items():
         assert np.abs(tr[:n_cl, OUT[n], 0] - ref[:n_cl, OUT[n]]).max() < t, (case, n)
-    assert np.abs(tr[:, :, 0] - tr[:, :, 1]).max() == 0.0
     if case == 11:
         Ts = OPT["Tvec"][0]
         v = ref[:, OUT["v"]]
@@ -342,3 +352,52 @@ def test_horizon_limits(N, torch_mod, lead_trace):
         assert rst.sum() == 0
         for n in ("s", "v", "Fm", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
             assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (N, i, n)
+
+
+def test_host_wrapper_equals_device_path(torch_mod, lead_trace):
+    """eepacc_run_abmpc_host (host numpy buffers in and out: the entry the MEX gateway mex/RunOpt_ABMPC.c
+    calls) against the device-pointer path and the ABO golden."""
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    G = load_golden("abo_abmpc")
+    eng = _engine(OPT, V, 4)
+    B, n = 3, 200
+    stv = np.repeat(s_tv[:n, None], B, 1); vtv = np.repeat(v_tv[:n, None], B, 1)
+    th, sh = eng.run_abmpc_host(np.zeros(B), np.zeros(B), np.zeros(B), stv, vtv)
+    td, sd = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv, vtv)
+    assert np.array_equal(th, td.cpu().numpy()) and np.array_equal(sh, sd.cpu().numpy())
+    assert sh.sum() == 0
+    for nm in ("s", "v", "Fm", "xi_v", "xi_h"):
+        assert np.abs(th[:, OUT[nm], 0] - G[nm + "_opt"][:n]).max() < TOL[nm], nm
+
+
+def test_handoff_timeout_is_reported(torch_mod, lead_trace, monkeypatch):
+    """Debug hook EEPACC_DEBUG_SPIN_LIMIT=0: a work unit whose predecessor is not yet published gives up at
+    once.  The unit must not continue from stale state: its steps carry status 3, the rest of the launch is
+    abandoned and eepacc_synchronize reports EEPACC_EDEVICE; after a reset the handle works again."""
+    from eepacc_mpc_casadi_matlab_amd.engine import EepaccError
+    OPT, V, _, _ = make_case("ABO", 20)
+    B, n_steps = 64, 80
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=5)
+    eng = _engine(OPT, V, B)
+    good, gst = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    eng.synchronize()
+    good = good.cpu().numpy()
+    monkeypatch.setenv("EEPACC_DEBUG_SPIN_LIMIT", "0")
+    traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    st = status.cpu().numpy()
+    if (st == 3).any():
+        with pytest.raises(EepaccError):
+            eng.synchronize()
+        ok = st != 3
+        # steps that were computed before the failure are the regular results
+        first_bad = np.argmax(st == 3, axis=0)
+        for i in range(B):
+            kb = first_bad[i] if (st[:, i] == 3).any() else n_steps
+            assert np.array_equal(traj.cpu().numpy()[:kb, :, i], good[:kb, :, i])
+            assert (st[kb:, i] == 3).all()
+    else:       # every predecessor happened to be published in time
+        eng.synchronize()
+    monkeypatch.delenv("EEPACC_DEBUG_SPIN_LIMIT")
+    again, ast = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    eng.synchronize()
+    assert np.array_equal(again.cpu().numpy(), good) and int(ast.cpu().numpy().sum()) == 0
