@@ -10,6 +10,7 @@
 #include "eepacc_device.h"
 #include "eepacc_qp_dense.h"
 #include "eepacc_fb.h"
+#include "eepacc_fbs.h"
 #include "../../include/eepacc.h"
 
 namespace eepacc {
@@ -63,6 +64,9 @@ struct eepacc_handle {
     double *fb_sp = nullptr, *fb_vp = nullptr;   // [N+1][fb_B] predictions of the last step
     int32_t* fb_qpstat = nullptr;
     int* fb_rhok = nullptr;                  // [fb_B] regularisation exponent found at the previous step
+    // structured FBMPC path (eepacc_fbs.hip): per-instance state, closed-loop carry, base-inverse scratch
+    bool fbs = false;                        // settings are covered by the structured solver
+    double *fbs_state = nullptr, *fbs_carry = nullptr, *fbs_hb = nullptr;
 };
 
 extern "C" const char* eepacc_last_error(void) { return g_err.c_str(); }
@@ -259,6 +263,18 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     HIPCHK(eepacc::set_max_smem());
+    // FBMPC: structured kernels unless the settings need the dense path (or EEPACC_FB_DENSE=1 asks for it)
+    h->fbs = eepacc::fbs_supported(C) && eepacc::fbs_smem_bytes(C.N) <= 152 * 1024;
+    if (const char* e = getenv("EEPACC_FB_DENSE")) if (atoi(e) != 0) h->fbs = false;
+    if (h->fbs) {
+        HIPCHK(eepacc::fbs_set_max_smem());
+        const size_t ns = (size_t)max_batch * eepacc::kFbsStateDoubles;
+        HIPCHK(hipMalloc(&h->fbs_state, ns * sizeof(double)));
+        HIPCHK(hipMemset(h->fbs_state, 0, ns * sizeof(double)));
+        HIPCHK(hipMalloc(&h->fbs_carry, (size_t)max_batch * 6 * sizeof(double)));
+        HIPCHK(hipMemset(h->fbs_carry, 0, (size_t)max_batch * 6 * sizeof(double)));
+        HIPCHK(hipMalloc(&h->fbs_hb, eepacc::fbs_hb_doubles(C.N, max_batch, h->num_cus) * sizeof(double)));
+    }
     guard.h = nullptr;
     *out = h;
     return EEPACC_OK;
@@ -287,6 +303,9 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_done) (void)hipFree(h->d_done);
     if (h->d_err) (void)hipFree(h->d_err);
+    if (h->fbs_state) (void)hipFree(h->fbs_state);
+    if (h->fbs_carry) (void)hipFree(h->fbs_carry);
+    if (h->fbs_hb) (void)hipFree(h->fbs_hb);
     if (h->d_qp_ws) (void)hipFree(h->d_qp_ws);
     if (h->d_qp_counter) (void)hipFree(h->d_qp_counter);
     fb_free(h);
@@ -301,6 +320,7 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     HIPCHK(hipMemset(h->d_err, 0, sizeof(int)));
     h->k_done = 0; h->carry_B = 0;
     h->fb_k_done = 0;
+    if (h->fbs_state) HIPCHK(hipMemset(h->fbs_state, 0, (size_t)h->max_batch * eepacc::kFbsStateDoubles * sizeof(double)));
     if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));
     if (h->fb_sp) {
         HIPCHK(hipMemset(h->fb_sp, 0, (size_t)h->fb_B * (h->cfg.N + 1) * sizeof(double)));
@@ -520,6 +540,16 @@ extern "C" int eepacc_fb_step(eepacc_handle* h, int B, const double* s, const do
     if (!s || !v || !a_prev || !t0 || !s_tv || !v_tv || !a_tv_prev || !out || !status)
         return fail(EEPACC_EINVAL, "eepacc_fb_step: NULL buffer");
     HIPCHK(hipSetDevice(h->device));
+    if (h->fbs) {
+        eepacc::fbs_step_args a;
+        a.cfg = h->d_cfg; a.B = B; a.k_step = h->fb_k_done;
+        a.s = s; a.v = v; a.a_prev = a_prev; a.t0 = t0; a.s_tv = s_tv; a.v_tv = v_tv; a.a_tv_prev = a_tv_prev;
+        a.state = h->fbs_state; a.hb = h->fbs_hb; a.out = out; a.s_pred = s_pred; a.v_pred = v_pred;
+        a.status = status; a.iters = h->d_iters;
+        HIPCHK(eepacc::launch_fbs_step(a, h->cfg.N, (hipStream_t)stream));
+        h->fb_k_done += 1; h->last_B = B;
+        return EEPACC_OK;
+    }
     int rc = fb_prepare(h, B);
     if (rc != EEPACC_OK) return rc;
     return fb_one_step(h, B, 0, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, out, s_pred, v_pred, status, (hipStream_t)stream);
@@ -536,6 +566,23 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
     HIPCHK(hipSetDevice(h->device));
     if (h->fb_k_done > 0 && B != h->last_B)
         return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: B changed while resuming; call eepacc_reset first");
+    if (h->fbs) {
+        static int chunk_steps = -1;
+        if (chunk_steps < 0) {
+            const char* ev = getenv("EEPACC_CHUNK");
+            chunk_steps = (ev && atoi(ev) > 0) ? atoi(ev) : 16;
+        }
+        eepacc::fbs_run_args a;
+        a.cfg = h->d_cfg; a.B = B; a.k_start = h->fb_k_done; a.n_steps = n_steps;
+        a.s0 = s0; a.v0 = v0; a.a_m1 = a_minus1; a.s_tv = s_tv; a.v_tv = v_tv;
+        a.carry = h->fbs_carry; a.state = h->fbs_state; a.hb = h->fbs_hb; a.traj = traj; a.status = status;
+        a.iters_total = h->d_iters; a.work_counter = h->d_counter; a.done = h->d_done; a.err_word = h->d_err;
+        a.chunk_steps = chunk_steps; a.spin_limit = 1 << 26;
+        if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) a.spin_limit = atoi(ev);
+        HIPCHK(eepacc::launch_fbs_run(a, h->cfg.N, h->num_cus, (hipStream_t)stream));
+        h->fb_k_done += n_steps; h->last_B = B;
+        return EEPACC_OK;
+    }
     int rc = fb_prepare(h, B);
     if (rc != EEPACC_OK) return rc;
     for (int kk = 0; kk < n_steps; ++kk) {

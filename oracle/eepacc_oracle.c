@@ -744,7 +744,8 @@ int orc_fb_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_loop_stat
     orc_transform_to_dense(N, nu, nC, A, Bm, Dm, Hs, cs, Gs, glb, gub, io->s, io->v, Hd, cd, Gd,
                            lbd, ubd, Psi, d);                                 /* :264 */
     double cost = 0.0;
-    orc_qp_solve_dense(nV, nC, Hd, cd, Gd, lbd, ubd, NULL, NULL, st->xwarm, 0.0, 0, x, &cost, &io->qp); /* :278 */
+    /* the FB dense Hessian is indefinite: spectral regularisation (qp_dense.c) */
+    orc_qp_solve_dense(nV, nC, Hd, cd, Gd, lbd, ubd, NULL, NULL, st->xwarm, -1e-8, 0, x, &cost, &io->qp); /* :278 */
     memcpy(st->xwarm, x, sizeof(double) * nV);
     for (int i = 0; i < nz; ++i) {
         double sacc = d[i];

@@ -101,6 +101,97 @@ static void lu_solve(const double* LU, const int* piv, int n, double* b) {
     }
 }
 
+/* Symmetric eigen-decomposition A = Z diag(d) Z' (Householder tridiagonalisation + implicit QL, the
+ * classical EISPACK pair tred2 / tql2; Wilkinson & Reinsch, Handbook for Automatic Computation II,
+ * 1971).  a: n x n row-major, overwritten by the eigenvectors (columns); d: eigenvalues.  returns 0 ok. */
+static int sym_eig(double* a, int n, double* d) {
+    double* e = (double*)calloc(n, sizeof(double));
+    for (int i = n - 1; i > 0; --i) {
+        int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += fabs(a[IDX(i, k, n)]);
+            if (scale == 0.0) e[i] = a[IDX(i, l, n)];
+            else {
+                for (int k = 0; k <= l; ++k) { a[IDX(i, k, n)] /= scale; h += a[IDX(i, k, n)] * a[IDX(i, k, n)]; }
+                double f = a[IDX(i, l, n)];
+                double g = f >= 0.0 ? -sqrt(h) : sqrt(h);
+                e[i] = scale * g; h -= f * g;
+                a[IDX(i, l, n)] = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    a[IDX(j, i, n)] = a[IDX(i, j, n)] / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += a[IDX(j, k, n)] * a[IDX(i, k, n)];
+                    for (int k = j + 1; k <= l; ++k) g += a[IDX(k, j, n)] * a[IDX(i, k, n)];
+                    e[j] = g / h;
+                    f += e[j] * a[IDX(i, j, n)];
+                }
+                double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = a[IDX(i, j, n)];
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) a[IDX(j, k, n)] -= f * e[k] + g * a[IDX(i, k, n)];
+                }
+            }
+        } else e[i] = a[IDX(i, l, n)];
+        d[i] = h;
+    }
+    d[0] = 0.0; e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        int l = i - 1;
+        if (d[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g += a[IDX(i, k, n)] * a[IDX(k, j, n)];
+                for (int k = 0; k <= l; ++k) a[IDX(k, j, n)] -= g * a[IDX(k, i, n)];
+            }
+        }
+        d[i] = a[IDX(i, i, n)];
+        a[IDX(i, i, n)] = 1.0;
+        for (int j = 0; j <= l; ++j) a[IDX(j, i, n)] = a[IDX(i, j, n)] = 0.0;
+    }
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    int rc = 0;
+    for (int l = 0; l < n && rc == 0; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) <= 2.3e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) { rc = -1; break; }
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i], b = c * e[i];
+                    e[i + 1] = (r = hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    for (int k = 0; k < n; ++k) {
+                        f = a[IDX(k, i + 1, n)];
+                        a[IDX(k, i + 1, n)] = s * a[IDX(k, i, n)] + c * f;
+                        a[IDX(k, i, n)] = c * a[IDX(k, i, n)] - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    free(e);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* one-sided constraint list  n_i' x >= b_i  built from the two-sided reference form     */
 
@@ -513,12 +604,51 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
     double hmax = 0.0;
     for (int i = 0; i < nV; ++i) if (fabs(H[IDX(i, i, nV)]) > hmax) hmax = fabs(H[IDX(i, i, nV)]);
     if (hmax == 0.0) hmax = 1.0;
-    if (rho_rel <= 0.0) rho_rel = 1e-7;
-    if (max_prox <= 0) max_prox = 8;
-    double rho = rho_rel * hmax;
-    /* an indefinite H (FB) needs rho above its most negative eigenvalue: bump until Cholesky
-     * of H + rho I succeeds */
-    for (int tries = 0; tries < 60; ++tries) {
+    /* Two regularisations of a Hessian that is not positive definite:
+     *  rho_rel >= 0 : H + rho I (uniform; what qpOASES does for positive SEMI-definite Hessians).  Enough for
+     *                 the AB QPs; on the indefinite FB Hessian rho has to exceed |lambda_min| ~ 0.1 and the
+     *                 proximal rounds then creep in every direction whose curvature is small against rho.
+     *  rho_rel <  0 : spectral modification H + M, M = Z diag(max(0, delta - lambda_i)) Z' with
+     *                 delta = |rho_rel| max|lambda|: eigenvalues below delta are lifted to delta, everything
+     *                 else is left alone, so the rounds are exact Newton steps in the curved directions and
+     *                 long steps (cost / delta, stopped by the constraints) in the flat or negative ones.  The
+     *                 fixed point is a KKT point of the unmodified problem (M (x - xc) vanishes there) and the
+     *                 exact KKT polish / verification below is the same for both. */
+    const int spectral = rho_rel < 0.0;
+    double* Mreg = NULL;
+    if (rho_rel == 0.0) rho_rel = 1e-7;
+    if (max_prox <= 0) max_prox = spectral ? 60 : 8;
+    double rho = fabs(rho_rel) * hmax;
+    if (spectral) {
+        double* Z = (double*)malloc(sizeof(double) * (size_t)nV * nV);
+        double* ev = (double*)malloc(sizeof(double) * nV);
+        Mreg = (double*)calloc((size_t)nV * nV, sizeof(double));
+        for (int i = 0; i < nV; ++i)
+            for (int j = 0; j < nV; ++j) Z[IDX(i, j, nV)] = 0.5 * (H[IDX(i, j, nV)] + H[IDX(j, i, nV)]);
+        if (sym_eig(Z, nV, ev) != 0) { free(Z); free(ev); free(Mreg); Mreg = NULL; }
+        else {
+            double emax = 0.0;
+            for (int i = 0; i < nV; ++i) if (fabs(ev[i]) > emax) emax = fabs(ev[i]);
+            if (emax == 0.0) emax = 1.0;
+            rho = fabs(rho_rel) * emax;
+            for (int k = 0; k < nV; ++k) {
+                const double add = rho - ev[k];
+                if (!(add > 0.0)) continue;
+                for (int i = 0; i < nV; ++i) {
+                    const double zi = add * Z[IDX(i, k, nV)];
+                    if (zi == 0.0) continue;
+                    for (int j = 0; j < nV; ++j) Mreg[IDX(i, j, nV)] += zi * Z[IDX(j, k, nV)];
+                }
+            }
+            for (int i = 0; i < nV; ++i)
+                for (int j = 0; j < nV; ++j)
+                    Gr[IDX(i, j, nV)] = 0.5 * (H[IDX(i, j, nV)] + H[IDX(j, i, nV)]) + 0.5 * (Mreg[IDX(i, j, nV)] + Mreg[IDX(j, i, nV)]);
+            free(Z); free(ev);
+        }
+    }
+    /* uniform mode: an indefinite H needs rho above its most negative eigenvalue: bump until Cholesky of
+     * H + rho I succeeds */
+    for (int tries = 0; tries < 60 && !Mreg; ++tries) {
         for (int i = 0; i < nV; ++i)
             for (int j = 0; j < nV; ++j)
                 Gr[IDX(i, j, nV)] = 0.5 * (H[IDX(i, j, nV)] + H[IDX(j, i, nV)]) + (i == j ? rho : 0.0);
@@ -557,9 +687,21 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
         free(taken);
     }
     for (int it = 0; it < max_prox; ++it) {
-        for (int i = 0; i < nV; ++i) gr[i] = g[i] - rho * xc[i];
+        if (Mreg) {
+            for (int i = 0; i < nV; ++i) {
+                double sacc = g[i];
+                for (int j = 0; j < nV; ++j) sacc -= 0.5 * (Mreg[IDX(i, j, nV)] + Mreg[IDX(j, i, nV)]) * xc[j];
+                gr[i] = sacc;
+            }
+        } else {
+            for (int i = 0; i < nV; ++i) gr[i] = g[i] - rho * xc[i];
+        }
         int iters = 0;
-        int rc = gi_solve(nV, Gr, gr, A, &C, crash, n_crash, x, act, u, &q, &iters, 20 * (nV + C.m) + 100);
+        /* spectral mode: later rounds start from the previous round's working set (entries whose multiplier
+         * turns negative for the new linear term are discarded by gi_solve) */
+        const int warm_ws = Mreg && it > 0 && q > 0;
+        if (warm_ws) memcpy(crash, act, sizeof(int) * q);
+        int rc = gi_solve(nV, Gr, gr, A, &C, crash, warm_ws ? q : n_crash, x, act, u, &q, &iters, 20 * (nV + C.m) + 100);
         tot_iters += iters;
         prox_used = it + 1;
         if (rc != 0) { status = 1; break; }
@@ -628,6 +770,7 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
         st->rho = rho;
     }
     free(crash);
+    free(Mreg);
     free_onesided(&C);
     free(Gr); free(gr); free(xc); free(xp); free(up); free(act); free(u);
     return status;

@@ -476,16 +476,80 @@ class StructuredFB:
         n, c = self.xi_expr(g)
         return -n, c - p.groups[g]["lb"]       # lb - xi <= 0
 
+    # ---- dual feasibility of a given state (warm start, or after the one discontinuous event "cap_in") -------
+    def reset_cold(self):
+        self.W = []; self.lam = {}
+        for st in self.gstate.values():
+            st.update(P=False, pivot=None, compl=False)
+        for st in self.wst:
+            st.update(P=False, pivot=None)
+
+    def repair(self, max_pass=40, verbose=False):
+        """multipliers of the current state; while one of them has the wrong sign fix the worst offender (drop the
+        row / switch a quadratic slack to its penalty / move a pivot) and recompute.  Returns the primal point."""
+        p = self.p
+        for it in range(max_pass):
+            try:
+                self.solve_multipliers()
+            except np.linalg.LinAlgError:
+                self.reset_cold(); continue
+            if self.refine_rounds:
+                self.refine(None, self.refine_rounds)
+            u = self.primal()
+            if self.unsupported:
+                return u
+            lam_max = max([abs(v) for v in self.lam.values()] + [0.0])
+            tol = self.warm_tol * (1.0 + lam_max)
+            worst, fix = tol, None
+            for j in self.W:
+                g = p.rows[j]["grp"]; lam = self.lam[j]
+                if -lam > worst:
+                    worst, fix = -lam, ("drop", j)
+                if g is not None and p.groups[g]["q"] > 0 and lam - p.groups[g]["w"] > worst:
+                    worst, fix = lam - p.groups[g]["w"], ("compl", j)
+            v = p.vbar[:self.N] + p.Sv[:self.N] @ u
+            for k in range(self.N):
+                wrel = self.w_relevant(k)
+                val = self.local_mults(k, lambda j: self.lam[j], p.c5 * v[k] + p.c2, True)
+                for key, x in val.items():
+                    if key[1] == "w" and not wrel:
+                        continue
+                    scale = 1.0 if key[1] == "w" else (1.0 + p.groups[key[1]]["w"])
+                    if -x > worst * scale:
+                        worst, fix = -x / scale, ("local", k, key)
+            if fix is None:
+                return u
+            if verbose:
+                print("  repair", it, fix, worst)
+            if fix[0] == "drop":
+                self.W.remove(fix[1]); del self.lam[fix[1]]
+            elif fix[0] == "compl":
+                self.W.remove(fix[1]); del self.lam[fix[1]]
+                self.gstate[p.rows[fix[1]]["grp"]]["compl"] = True
+            else:
+                k, key = fix[1], fix[2]
+                var = key[1]; is_w = var == "w"
+                st = self.wst[k] if is_w else self.gstate[var]
+                cands = self.members(k, var, ("none",), 0.0)
+                if not is_w and self.wst[k]["P"]:
+                    cands = [c for c in cands if p.rows[c[0]]["aw"] == 0] or cands
+                if cands:
+                    j = max(cands, key=lambda c: c[1])[0]
+                    self.W.remove(j); del self.lam[j]
+                    st["P"] = True; st["pivot"] = j
+                else:
+                    st["P"] = False; st["pivot"] = None
+        self.reset_cold()
+        self.solve_multipliers()
+        return self.primal()
+
     # ---- main loop ----------------------------------------------------------------------------------------
     def solve(self, max_iter=2000, verbose=False):
         p = self.p
         self.status = 0
         self.factor()
         while True:
-            self.solve_multipliers()
-            if self.refine_rounds:
-                self.refine(None, self.refine_rounds)
-            u = self.primal()
+            u = self.repair(verbose=verbose)
             q = self.most_violated(u)
             if q is None or self.unsupported:
                 break
