@@ -579,6 +579,8 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
         a.iters_total = h->d_iters; a.work_counter = h->d_counter; a.done = h->d_done; a.err_word = h->d_err;
         a.chunk_steps = chunk_steps; a.spin_limit = 1 << 26;
         if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) a.spin_limit = atoi(ev);
+        a.cold = 0;
+        if (const char* ev = getenv("EEPACC_DEBUG_FBS_COLD")) a.cold = atoi(ev) != 0;
         HIPCHK(eepacc::launch_fbs_run(a, h->cfg.N, h->num_cus, (hipStream_t)stream));
         h->fb_k_done += n_steps; h->last_B = B;
         return EEPACC_OK;

@@ -33,6 +33,7 @@ struct fbs_run_args {           // B1: closed loop (ABO/RunOpt_FBMPC.m:161-331)
     int32_t *status, *iters_total;
     int *work_counter, *done, *err_word;
     int chunk_steps, spin_limit;
+    int cold;                   // debug: 1 = no working-set warm start between MPC steps
 };
 
 bool fbs_supported(const DevCfg& C);

@@ -904,6 +904,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         if (fast_run > 0 && rel0 > 1e-10) p_stale = true;
         if (warm) {
             const int rep = warm_repair(L, c, M, m, pass < kSinglePasses, F.drop_pos);
+#ifdef EEPACC_FBS_DEBUG
+            if (lane == 0 && rep) printf("  repair pass %d rep %d m %d\n", pass, rep, m);
+#endif
             if (rep == 2) F.fast = 2;
             if (rep) {
                 if (++pass >= kSinglePasses + 6) {
@@ -1061,6 +1064,10 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             st.status = 1; break;
         }
         lam_q += tstep;
+#ifdef EEPACC_FBS_DEBUG
+        if (lane == 0) printf("  it %d q k=%d code=%d viol %.3e t %.3e %s ev=%d lane=%d t=%d m %d zz %.3e\n", st.iters, kq, q.qcode, viol, tstep,
+                              t2 <= t1 ? "full" : "event", ev >> 16, (ev >> 5) & 63, ev & 31, m, zz);
+#endif
         bool finished = false;
         if (t2 <= t1) {
             // full step: the incoming constraint becomes active
@@ -1307,6 +1314,10 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
         }
         WSYNC();
     }
+#ifdef EEPACC_FBS_DEBUG
+    if (lane < N) printf("DBG lane %d g0 %.15e Pi %.15e gam %.15e vbar %.15e H0 %.15e H5 %.15e Hd %.15e A22 %.15e D2 %.15e\n", lane, L.g0, L.Pi, L.gam, L.vbar,
+                         Hs[0 * NS + lane], Hs[5 * NS + lane], Hs[lane * NS + lane], A22, D2);
+#endif
     // in-place inverse by symmetric sweeps (H is positive definite: cond ~ 1e2); afterwards Hs = -H^-1
     int h_bad = 0;
     for (int k = 0; k < N; ++k) {
@@ -1374,7 +1385,7 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
                 exists = false;
                 const int g2 = group_of(t);
                 const double need = -bat;
-                if (g2 == GN) { if (need > 1e-9) infeasible_const = 1; }
+                if (g2 == GN) { if (need > kTolViol * (1.0 + fabs(b[t]))) infeasible_const = 1; }   // the dense solver's row tolerance
                 else if (g2 == GF) L.lbF = fmax(L.lbF, need);
                 else if (g2 == GS) L.lbS = fmax(L.lbS, need);
                 else if (g2 == GV) L.lbV = fmax(L.lbV, need);
@@ -1398,6 +1409,9 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     SolveStats st{2, 0, 0, 0};
     if (!h_bad) st = solve_qp<MMAX, NS>(L, c, M, Hs, Hb, 16 * N + 100, grad_total);
     code = L.code;
+#ifdef EEPACC_FBS_DEBUG
+    if (lane <= N) printf("FIN lane %d code %llx u %.15e ign %x valid %x st %d iters %d m %d\n", lane, L.code, L.u, L.ign, L.valid, st.status, st.iters, st.m);
+#endif
     // recover z = Psi x + d (F4): predicted states, stage-0 controls and slacks
     s_pred = sbar + L.sh; v_pred = L.vbar + L.vh;
     const Locals S = locals_of<NS>(L, c, M.ba);
@@ -1591,7 +1605,7 @@ k_fbs_run(fbs_run_args a) {
                 ps = __shfl(sp, idx, 64); pv = __shfl(vp, idx, 64);
             }
             if (kk == kk1 - 1 && lane <= N) { st_sp(stt)[lane] = sp; st_vp(stt)[lane] = vp; }
-            code = shift_codes(code, N);
+            code = a.cold ? 0ull : shift_codes(code, N);
             write_out(a.traj + (size_t)kk * EEPACC_OUT_N * B + b, (size_t)B, so, lane);
             if (lane == 0) a.status[(size_t)kk * B + b] = so.status;
             it_total += so.iters;

@@ -746,6 +746,33 @@ int orc_fb_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_loop_stat
     double cost = 0.0;
     /* the FB dense Hessian is indefinite: spectral regularisation (qp_dense.c) */
     orc_qp_solve_dense(nV, nC, Hd, cd, Gd, lbd, ubd, NULL, NULL, st->xwarm, -1e-8, 0, x, &cost, &io->qp); /* :278 */
+    /* The FB QP is non-convex (bilinear speed x motor-force power term): it can have several KKT points.  Where
+     * the predicted speed is zero the split of the total force into motor and friction brake costs nothing, and a
+     * proximal sequence that passed through a braking phase can settle on a point of that flat face with the
+     * friction brake still applied, which then pins the speed at zero (a local solution with a higher objective).
+     * The reference's saved solutions never use the friction brake (Fb_opt = 0 for k >= 1), so the solve is
+     * repeated from the same point with the friction brake released and the solution with the lower objective
+     * is kept. */
+    {
+        int braking = 0;
+        for (int k = 0; k < N; ++k) if (x[k * nu + 1] < -1e-6) braking = 1;
+        if (braking) {
+            double* x0b = (double*)malloc(sizeof(double) * nV);
+            double* xb = (double*)calloc(nV, sizeof(double));
+            double costb = 0.0;
+            orc_qp_stats qb;
+            memcpy(x0b, x, sizeof(double) * nV);
+            for (int k = 0; k < N; ++k) { x0b[k * nu] += x0b[k * nu + 1]; x0b[k * nu + 1] = 0.0; }
+            orc_qp_solve_dense(nV, nC, Hd, cd, Gd, lbd, ubd, NULL, NULL, x0b, -1e-8, 0, xb, &costb, &qb);
+            if (qb.status == 0 && (io->qp.status != 0 || costb < cost - 1e-12 * fabs(cost))) {
+                memcpy(x, xb, sizeof(double) * nV);
+                cost = costb;
+                qb.iterations += io->qp.iterations;
+                io->qp = qb;
+            }
+            free(x0b); free(xb);
+        }
+    }
     memcpy(st->xwarm, x, sizeof(double) * nV);
     for (int i = 0; i < nz; ++i) {
         double sacc = d[i];

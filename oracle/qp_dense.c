@@ -615,6 +615,7 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
      *                 fixed point is a KKT point of the unmodified problem (M (x - xc) vanishes there) and the
      *                 exact KKT polish / verification below is the same for both. */
     const int spectral = rho_rel < 0.0;
+    int gi_failed = 0;
     double* Mreg = NULL;
     if (rho_rel == 0.0) rho_rel = 1e-7;
     if (max_prox <= 0) max_prox = spectral ? 60 : 8;
@@ -704,7 +705,7 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
         int rc = gi_solve(nV, Gr, gr, A, &C, crash, warm_ws ? q : n_crash, x, act, u, &q, &iters, 20 * (nV + C.m) + 100);
         tot_iters += iters;
         prox_used = it + 1;
-        if (rc != 0) { status = 1; break; }
+        if (rc != 0) { status = 1; gi_failed = 1; break; }
         /* exact polish on the identified working set */
         memcpy(xp, x, sizeof(double) * nV);
         int prc = kkt_polish(nV, H, g, A, &C, act, q, xp, up, kkt);
@@ -773,5 +774,10 @@ int orc_qp_solve_dense(int nV, int nC, const double* H, const double* g, const d
     free(Mreg);
     free_onesided(&C);
     free(Gr); free(gr); free(xc); free(xp); free(up); free(act); free(u);
+    /* spectral mode: a floor of 1e-8 max|lambda| leaves the regularised Hessian with a condition number of 1e8, at
+     * which the dual active set can misjudge a linear dependence among many active rows (seen with the equality rows
+     * of blocked moves).  A failed inner solve is repeated with a hundred times larger floor (more, shorter rounds). */
+    if (status != 0 && gi_failed && spectral && fabs(rho_rel) < 1e-4)
+        return orc_qp_solve_dense(nV, nC, H, g, A, lba, uba, lbx, ubx, x0, rho_rel * 100.0, max_prox, x, cost, st);
     return status;
 }
