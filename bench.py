@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark: ABMPC N=30 dense-QP MPC steps per second at batch 4096 (BASELINE.json).
+"""Headline benchmark: ABMPC N=30 dense-QP MPC steps per second at batch 4096 (BASELINE.json configs[1]);
+`--workload fbmpc` runs BASELINE configs[2] (FBMPC N=30, batch 4096) under the same contract.
 
-One "step" = one receding-horizon step (estimate -> condense -> QP -> allocate -> plant) for all
-4096 synthetic S2 scenarios of a GPU (eepacc_mpc_casadi_matlab_amd/scenarios.py).  The timed
-region runs K consecutive closed-loop steps (after W warm-up steps of the same simulation) with
-all inputs resident in HBM; value = instances * K / time over all ranks.
+One "step" = one receding-horizon step (measure -> estimate -> condense -> QP -> extract/allocate -> plant) for all
+4096 synthetic S2 scenarios of a GPU (eepacc_mpc_casadi_matlab_amd/scenarios.py).  The timed region runs K consecutive
+closed-loop steps (after W warm-up steps of the same simulation) with all inputs resident in HBM;
+value = instances * K / time over all ranks.
 
     python bench.py --gpus 1 --steps 200 --warmup 200
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+The `roofline` block states the bound that binds these fused kernels (primary definition):
+fp64 vector issue.  HBM does not bind (about 0.2 KB of compulsory traffic per QP step) and there is no dense
+contraction for MFMA.  achieved = fp64 flops the kernel executes per QP step (PMC counters of the committed profile of
+this same command, profiles/r02_*_summary.json: SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes x active-lane fraction)
+x QP steps per launch / mean launch time measured live with HIP events.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -21,6 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP64_VALU_TFLOPS = 78.6        # MI355X vector fp64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 
 
 def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
@@ -56,106 +64,142 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
                            "sample": "%d instances x %d steps, one instance per thread" % (n_all, n_steps)})
 
 
-def main():
+def profile_figures(fb: bool, N: int):
+    """Per-QP-step figures of the dominant kernel from the committed PMC profile of this command."""
+    path = os.path.join(ROOT, "profiles", "r02_%s_N%d_summary.json" % ("fb" if fb else "ab", N))
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, os.path.relpath(path, ROOT)
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", choices=["abmpc", "fbmpc"], default="abmpc",
                     help="abmpc: the headline (BASELINE.json configs[1]); fbmpc: configs[2], same contract")
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap
 
+
+def run_bench(args, make_engine=None, device=None, backend=None):
+    """The benchmark job of one rank.  make_engine(OPT, V, device, B) builds the engine (default: the HIP engine);
+    device / backend let the CPU test drive the same flow over gloo with a stand-in engine.  Returns the result
+    dict on rank 0, None on the other ranks."""
     import torch
     import torch.distributed as dist
     from conftest import make_case
-    from eepacc_mpc_casadi_matlab_amd.engine import Engine
     from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
     from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
-
-    from eepacc_mpc_casadi_matlab_amd.distributed import rank_world, shard_range, reduce_kpis, max_over_ranks
+    from eepacc_mpc_casadi_matlab_amd.distributed import (rank_world, shard_range, local_kpis, reduce_kpis, kpi_dict,
+                                                          max_over_ranks)
     rank, world, local_rank = rank_world()
     # one rank per GPU over RCCL ("nccl"); EEPACC_DIST_BACKEND=gloo rehearses the multi-rank flow on fewer
-    # GPUs than ranks (ranks then share devices round-robin and the KPI vector is reduced on the host)
-    backend = os.environ.get("EEPACC_DIST_BACKEND", "nccl")
-    dev = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    # GPUs than ranks (ranks then share devices round-robin and the KPI tensors are reduced on the host)
+    backend = backend or os.environ.get("EEPACC_DIST_BACKEND", "nccl")
+    on_gpu = device is None
+    if on_gpu:
+        n_dev = max(1, torch.cuda.device_count())
+        dev = local_rank % n_dev
+        d = torch.device("cuda", dev)
+    else:
+        n_dev, dev, d = 1, 0, device
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(dev)
+        if on_gpu:
+            torch.cuda.set_device(dev)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=d)
         else:
             dist.init_process_group(backend)
     fb = args.workload == "fbmpc"
-    K = args.steps if args.steps is not None else (6 if fb else 200)
-    # default warm-up = one launch of the same size as the timed one, so that the per-kernel average
-    # of a rocprofv3 --stats run of the default command is the timed launch's duration
-    W = args.warmup if args.warmup is not None else (2 if fb else 200)
+    K, W = args.steps, args.warmup
     N, B = args.horizon, args.batch
     OPT, V, _, _ = make_case("ABO", N)
+    Ts = float(OPT["Tvec"][0])
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
     lo, _ = shard_range(rank, world, B)                                  # rank r owns instances [rB, (r+1)B)
     sc = make_s2(B, W + K, lead["V_TO_2Hz"], first_instance=lo)
-    eng = Engine(OPT, V, device=dev, max_batch=B)
-    d = torch.device("cuda", dev)
+    if make_engine is None:
+        from eepacc_mpc_casadi_matlab_amd.engine import Engine
+        make_engine = lambda OPT_, V_, dev_, B_: Engine(OPT_, V_, device=dev_, max_batch=B_)
+    eng = make_engine(OPT, V, dev, B)
     s_tv = torch.as_tensor(sc["s_tv"], device=d); v_tv = torch.as_tensor(sc["v_tv"], device=d)
     s0 = torch.as_tensor(sc["s0"], device=d); v0 = torch.as_tensor(sc["v0"], device=d); am1 = torch.as_tensor(sc["a_minus1"], device=d)
     chunk = args.chunk if args.chunk > 0 else K
 
-    # outputs are preallocated once (the caller owns all buffers, include/eepacc.h)
-    buf = (torch.empty((max(chunk, W), OUT_N, B), dtype=torch.float64, device=d),
-           torch.empty((max(chunk, W), B), dtype=torch.int32, device=d))
+    # outputs are preallocated once (the caller owns all buffers, include/eepacc.h); the timed window keeps its whole
+    # trajectory for the key figures
+    traj_all = torch.empty((max(K, W, 1), OUT_N, B), dtype=torch.float64, device=d)
+    stat_all = torch.empty((max(K, W, 1), B), dtype=torch.int32, device=d)
 
-    def run(lo, hi, resume):
+    def run(lo_, hi_, resume, off):
         f = eng.run_fbmpc if fb else eng.run_abmpc
-        return f(s0, v0, am1, s_tv[lo:hi], v_tv[lo:hi], resume=resume, out=buf)
+        n = hi_ - lo_
+        return f(s0, v0, am1, s_tv[lo_:hi_], v_tv[lo_:hi_], resume=resume, out=(traj_all[off:off + n], stat_all[off:off + n]))
 
-    def kpis(traj, bad):
-        # the quantities Main.m:203-263 prints, reduced over this rank's instances
-        return torch.stack([bad.to(torch.float64), traj[-1, OUT["s"]].sum(), (traj[:, OUT["a"]] ** 2).sum()])
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    # warm-up: W untimed steps of the simulation; also loads the code objects of every kernel the
-    # timed region launches (ours and torch's small reductions, which are loaded lazily)
+    cutoff = float(OPT.get("cutOffDist", 1000.0))
+
+    def kpis(n):
+        # the key figures Main.m:203-263 prints, for this rank's instances over the window (energy: A10 post-processing)
+        E = eng.postprocess(traj_all[:n])[3]
+        return local_kpis(traj_all[:n], stat_all[:n], E, Ts, cutoff, OUT)
+
+    # warm-up: W untimed steps of the simulation; also loads the code objects of every kernel the timed region
+    # launches (ours and torch's small reductions, which are loaded lazily) and runs the collectives once
     if W > 0:
-        tw, sw = run(0, W, False)
-    else:                              # no warm-up steps asked for: still load the small reduction kernels below
-        tw, sw = buf[0][:1].zero_(), buf[1][:1].zero_()
-    bad_w = torch.zeros((), dtype=torch.int64, device=d)
-    bad_w += sw.sum()                  # the same in-place int64 add the timed loop issues (a lazily loaded kernel costs ~10 ms)
-    kw = reduce_kpis(kpis(tw, bad_w) if backend == "nccl" else kpis(tw, bad_w).cpu(), world)
-    torch.cuda.synchronize()
+        run(0, W, False, 0)
+        kw = kpis(W)
+    else:
+        traj_all[:1].zero_(); stat_all[:1].zero_()
+        kw = kpis(1)
+    kw = tuple(x if backend == "nccl" else x.cpu() for x in kw)
+    reduce_kpis(*kw, world)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    stream = torch.cuda.current_stream(d)
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    sync()
+    if on_gpu:
+        stream = torch.cuda.current_stream(d)      # the stream the engine launches on (engine._stream)
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
+    if on_gpu:
+        ev0.record(stream)
     launches = 0
-    bad = torch.zeros((), dtype=torch.int64, device=d)
-    energy = torch.zeros((), dtype=torch.float64, device=d)
     k = W
     while k < W + K:
         hi = min(k + chunk, W + K)
-        traj, status = run(k, hi, resume=(k > 0))
+        run(k, hi, k > 0, k - W)
         launches += 1
-        bad += status.sum()
         k = hi
-    ev1.record(stream)
-    # KPI reduction (the only collective of the job): bad exits, distance, sum a^2
-    kpi = reduce_kpis(kpis(traj, bad) if backend == "nccl" else kpis(traj, bad).cpu(), world)
-    torch.cuda.synchronize()
+    if on_gpu:
+        ev1.record(stream)
+    # key-figure reduction: the only collectives of the job (SUM, MIN, MAX of three small tensors)
+    kp = kpis(K)
+    kp = tuple(x if backend == "nccl" else x.cpu() for x in kp)
+    sums, mins, maxs = reduce_kpis(*kp, world)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
+    kernel_ms = ev0.elapsed_time(ev1) if on_gpu else dt * 1e3
     dt = max_over_ranks(dt, world, d if backend == "nccl" else None)
+    if hasattr(eng, "synchronize"):
+        eng.synchronize()                       # raises if the closed-loop kernel flagged a device-side failure
     iters = eng.last_iterations(B)
+    neg_v = int((traj_all[:K, OUT["v"]] < -1e-11).sum().item())
 
+    res = None
     if rank == 0:
         total_steps = world * B * K
         value = total_steps / dt
@@ -164,61 +208,69 @@ def main():
         bytes_fused = 152                                                          # SURVEY 8d, R-fused (compulsory)
         launch_s = (kernel_ms / 1e3) / launches
         qp_per_launch = B * (K / launches)
-        achieved_mat = bytes_mat * qp_per_launch / launch_s / 1e9
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, KB units, raw)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
-            per_qp = (prof["pmc"]["FETCH_SIZE"] + prof["pmc"]["WRITE_SIZE"]) * 1024.0 / (4096 * 200)
-            traffic = per_qp * qp_per_launch
-        except Exception:
-            pass
-        kname = "k_qp_dense (+ k_fb_build, k_fb_apply)" if fb else "k_run_abmpc"
-        if fb:
-            traffic = None
-            try:   # raw FETCH_SIZE + WRITE_SIZE (KB) of one k_qp_dense launch at this size; 8-byte-per-lane accesses, uncalibrated
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_fb_summary.json")))
-                traffic = (prof["pmc"]["FETCH_SIZE"] + prof["pmc"]["WRITE_SIZE"]) * 1024.0
-            except Exception:
-                pass
-            launches = K                    # one build + QP + extraction launch group per MPC step
-            launch_s = (kernel_ms / 1e3) / launches
-            qp_per_launch = B
-            achieved_mat = bytes_mat * qp_per_launch / launch_s / 1e9
+        qp_rate = qp_per_launch / launch_s                                         # QP steps/s of this rank's kernel
+        prof, prof_path = profile_figures(fb, N)
+        kname = "k_fbs_run" if fb else "k_run_abmpc"
+        if prof is not None:
+            ps = prof["per_qp_step"]
+            flops = ps["fp64_flops_active_lanes"]
+            achieved = flops * qp_rate / 1e12
+            roof = {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP64_VALU_TFLOPS,
+                    "traffic": ps["hbm_bytes_fetch_plus_write"] * qp_per_launch,
+                    "traffic_note": "FETCH_SIZE + WRITE_SIZE per QP step of the committed profile (%s; 8-byte-per-lane accesses, "
+                                    "uncalibrated: MI355X_MICROARCH.md HBM section) x QP steps of this launch" % prof_path,
+                    "definition": "SURVEY.md 8d primary: fp64 flops executed per QP step (%s: (ADD + MUL + 2 FMA)_F64 wave instructions "
+                                  "x 64 lanes x active-lane fraction %.2f = %.0f flop) x QP steps per launch / mean launch time (HIP events, "
+                                  "this run) against the vector-fp64 peak; HBM does not bind (compulsory traffic ~%d B per QP step) and "
+                                  "the kernel has no dense contraction for MFMA" % (prof_path, ps["active_lane_fraction"], flops, bytes_fused),
+                    "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3,
+                    "valu_issue_util": prof["derived"]["valu_issue_util"],
+                    "fp64_pipe_util_all_lanes": ps["fp64_flops_all_lanes"] * qp_rate / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                    "wave_cycles_waiting": prof["derived"]["wave_cycles_waiting"],
+                    "occupancy_waves_per_simd": prof["derived"]["waves_per_simd"]}
+        else:
+            roof = {"bound": "valu_fp64", "achieved": None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "definition": "no committed PMC profile for this workload (%s)" % prof_path,
+                    "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3}
+        it_step = float(iters.mean()) / max(K / launches, 1)
         res = {
             "metric": "QP steps/sec (whole node), %s N=%d dense QP at batch %d" % ("FBMPC" if fb else "ABMPC", N, B),
-            "value": value, "unit": "QP steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "QP steps/s", "n_gpus": min(world, n_dev) if on_gpu else 0, "ranks": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s N=%d fp64, batch=%d synthetic S2 ego/lead scenarios per GPU, closed loop"
                                    % ("FBMPC" if fb else "ABMPC", N, B),
                        "batch_per_gpu": B, "horizon": N, "steps_per_launch": int(K / launches),
                        "parallelism": "instances sharded across %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved_mat, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved_mat / 8000.0, "traffic": traffic,
-                         "definition": "R-materialised (SURVEY.md 8d): bytes the reference's dense-QP API moves per QP step "
-                                       "(%d B at N=%d) x QP steps per launch / mean launch time (HIP events)%s"
-                                       % (bytes_mat, N, "; FBMPC materialises exactly this QP in HBM for the dense QP operator" if fb else
-                                          "; the fused kernel's compulsory HBM traffic is only ~%d B/step, so HBM does not bind it and a fraction above 1 "
-                                          "just says: faster than any implementation that moves the materialised QP through HBM" % bytes_fused),
-                         "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3},
-            # the other two yardsticks of SURVEY.md 8d, for the record: compulsory ("R-fused") HBM bytes, and
-            # the algorithmic flops of the literal dense path (F_cond + n_iter F_iter, n_a ~ 4N) against the
-            # vector-fp64 peak; neither binds the fused kernel
-            "alt_rooflines": None if fb else {
-                "r_fused_hbm": {"bytes_per_step": bytes_fused, "achieved_GBps": bytes_fused * qp_per_launch / launch_s / 1e9,
-                                "frac": bytes_fused * qp_per_launch / launch_s / 1e9 / 8000.0},
-                "dense_path_fp64": (lambda it: {"flops_per_step": 2 * N ** 3 + 2 * nC * N + it * (4 * (4 * N) ** 2 + 2 * nC * N),
-                                                "achieved_TFLOPs": (2 * N ** 3 + 2 * nC * N + it * (4 * (4 * N) ** 2 + 2 * nC * N)) * qp_per_launch / launch_s / 1e12,
-                                                "peak_TFLOPs": 78.6})(float(iters.mean()) / (K / launches))},
-            "solver": {"mean_active_set_iterations_per_step": float(iters.mean()) / (1 if fb else K / launches),
-                       "bad_exits": int(kpi[0].item())},
-            "kpi": {"distance_sum_m": float(kpi[1].item()), "sum_a2": float(kpi[2].item())},
+            "roofline": roof,
+            # comparison figures only: what the reference's dense-QP API would move per QP step, and the
+            # compulsory traffic of the fused step
+            "comparison_figures": {
+                "r_materialised_hbm": {"bytes_per_qp_step": bytes_mat, "as_if_GBps": bytes_mat * qp_rate / 1e9,
+                                       "note": "bytes the reference's dense QP API moves; the fused kernels never materialise them"},
+                "r_fused_hbm": {"bytes_per_qp_step": bytes_fused, "achieved_GBps": bytes_fused * qp_rate / 1e9}},
+            "solver": {"mean_active_set_iterations_per_step": it_step, "bad_exits": int(round(float(sums[0]))),
+                       "bad_exits_with_infeasible_measured_state": neg_v,
+                       "note": "a measured speed below zero (after a stop behind a stopped lead) violates the hard row v_0 >= 0 "
+                               "of the reference QP: that QP has no solution, the reference reports exitMessage = 1 as well"},
+            "kpi": kpi_dict(sums, mins, maxs),
         }
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 2, 8) if fb else cpu_baseline(OPT, V, sc)      # ~10-20 s of host work
+        if shared := (world > 1 and on_gpu and world > n_dev):
+            res["note"] = "rehearsal: %d ranks share %d device(s)" % (world, n_dev)
+        if not args.no_cpu_baseline and world == 1 and on_gpu:      # reported at N = 1 only
+            res["cpu_baseline"] = cpu_baseline(OPT, V, sc, "fb", 2, 60) if fb else cpu_baseline(OPT, V, sc)      # ~10-25 s of host work
             res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    return res
+
+
+def main():
+    args = build_parser().parse_args()
+    import torch.distributed as dist
+    res = run_bench(args)
+    if res is not None:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -27,6 +27,7 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start
 hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double* traj, double* rpm, double* Tm,
                               double* P, double* E, hipStream_t stream);
 hipError_t set_max_smem();
+int pick_chunk_steps(int n_steps, int B, int resident_waves);
 }  // namespace eepacc
 
 using eepacc::DevCfg;
@@ -567,11 +568,8 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
     if (h->fb_k_done > 0 && B != h->last_B)
         return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: B changed while resuming; call eepacc_reset first");
     if (h->fbs) {
-        static int chunk_steps = -1;
-        if (chunk_steps < 0) {
-            const char* ev = getenv("EEPACC_CHUNK");
-            chunk_steps = (ev && atoi(ev) > 0) ? atoi(ev) : 16;
-        }
+        // work-unit length: 16 MPC steps, shorter for short launches so that every resident wave still gets several units
+        int chunk_steps = eepacc::pick_chunk_steps(n_steps, B, h->num_cus * 6);
         eepacc::fbs_run_args a;
         a.cfg = h->d_cfg; a.B = B; a.k_start = h->fb_k_done; a.n_steps = n_steps;
         a.s0 = s0; a.v0 = v0; a.a_m1 = a_minus1; a.s_tv = s_tv; a.v_tv = v_tv;

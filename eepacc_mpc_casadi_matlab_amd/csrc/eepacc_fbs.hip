@@ -36,6 +36,17 @@ using namespace wv;
 
 #define WSYNC() EEPACC_WSYNC()
 
+#ifdef EEPACC_FBS_TIMING
+__device__ unsigned long long g_fbs_prof[16];
+#define FT_DECL long long _ft = wall_clock64(); long long _fp[16] = {0}
+#define FT_TOC(slot) do { long long _n = wall_clock64(); _fp[slot] += _n - _ft; _ft = _n; } while (0)
+#define FT_FLUSH() do { if (lane_id() == 0) for (int _i = 0; _i < 16; ++_i) if (_fp[_i]) atomicAdd(&g_fbs_prof[_i], (unsigned long long)_fp[_i]); } while (0)
+#else
+#define FT_DECL
+#define FT_TOC(slot)
+#define FT_FLUSH()
+#endif
+
 constexpr double kInf = 1e300;
 constexpr double kTolViol = 1e-11;
 constexpr double kTolDual = 1e-12;
@@ -155,17 +166,24 @@ __device__ __forceinline__ double group_lb(const Lane& L, int g) { return g == G
 
 template <int NS> __device__ __forceinline__ double ba_of(const double* ba, int t, int lane) { return ba[t * (NS + 1) + lane]; }
 
+// bit tricks on the 2-bit codes: bit 2t of the result is set where type t has the given code
+constexpr unsigned long long kEven = 0x5555555555555555ull;
+__device__ __forceinline__ unsigned long long codes_eq1(unsigned long long c) { return c & ~(c >> 1) & kEven; }
+__device__ __forceinline__ unsigned long long codes_eq2(unsigned long long c) { return (c >> 1) & ~c & kEven; }
+__device__ __forceinline__ unsigned long long codes_eq3(unsigned long long c) { return (c >> 1) & c & kEven; }
+__device__ __forceinline__ constexpr unsigned long long type_range(int t0, int t1) {      // even bits of types t0..t1
+    return (((t1 >= 31) ? ~0ull : ((1ull << (2 * (t1 + 1))) - 1ull)) & ~((1ull << (2 * t0)) - 1ull)) & kEven;
+}
 // pivot type of linear group g at this lane (-1: the group's slack is on its bound)
 __device__ __forceinline__ int pivot_of(const Lane& L, int g) {
-    int p = -1;
-#pragma unroll
-    for (int t = F_TQMIN; t <= F_VINC; ++t)
-        if (group_of(t) == g && code_of(L, t) == 2) p = t;
-    return p;
+    const unsigned long long rng = g == GF ? type_range(F_TQMIN, F_VCURV) : (g == GS ? type_range(F_SAFE1, F_VTL) : type_range(F_VINC, F_VINC));
+    const unsigned long long two = codes_eq2(L.code) & rng;
+    return two ? ((__ffsll((long long)two) - 1) >> 1) : -1;
 }
 __device__ __forceinline__ int wpivot_of(const Lane& L) {
     if (L.lane >= L.N) return -1;
-    return code_of(L, F_FMLO) == 3 ? F_FMLO : (code_of(L, F_TQMIN) == 3 ? F_TQMIN : (code_of(L, F_RTLO) == 3 ? F_RTLO : -1));
+    const unsigned long long three = codes_eq3(L.code) & ((1ull << (2 * F_FMLO)) | (1ull << (2 * F_TQMIN)) | (1ull << (2 * F_RTLO)));
+    return three ? ((__ffsll((long long)three) - 1) >> 1) : -1;
 }
 
 // homogeneous response to the per-lane input x (lane k < N holds x_k): vh_k = Pi_k sum_{i<k} gamma_i x_i,
@@ -379,6 +397,7 @@ __device__ __forceinline__ void he_sync(Lane& L, const RC& c, FMem<MMAX, NS>& M,
     }
     L.kmask = want;
     // bilinear terms of the stages whose w is off its bound
+    if (L.wmask == 0ull && !__any(wpivot_of(L) >= 0)) return;
     const Tup XF = xi_expr<NS>(L, c, M.ba, GF);
     const Tup W = w_expr<NS>(L, c, M.ba, XF);
     const bool wantP = wpivot_of(L) >= 0;
@@ -428,9 +447,7 @@ template <int MMAX, int NS>
 __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMAX, NS>& M, double* Hs, const FastInfo& F) {
     const int lane = L.lane, N = L.N;
     he_sync(L, c, M, Hs);
-    int cnt = 0;
-#pragma unroll
-    for (int t = 0; t < kNumF; ++t) cnt += (code_of(L, t) == 1) ? 1 : 0;
+    const int cnt = __popcll(codes_eq1(L.code));
     L.base = (int)(scan_excl((double)cnt) + 0.5);
     const int m = (int)(wave_sum((double)cnt) + 0.5);
     if (m > MMAX) return -2;
@@ -451,9 +468,7 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMA
     if (m == 0) return 0;
     const unsigned short* rc = rc_table<MMAX>();
     if (F.fast == 1 && m == F.m_old + 1 && F.m_old > 0) {
-        int pl = 0;
-#pragma unroll
-        for (int t = 0; t < kNumF; ++t) pl += (t < F.tq && code_of(L, t) == 1) ? 1 : 0;
+        const int pl = __popcll(codes_eq1(L.code) & ((1ull << (2 * F.tq)) - 1ull));
         const int p = bcast_i(L.base + pl, F.kq);
         const double iz = 1.0 / F.zz;
         const int nnz = m * (m + 1) / 2;
@@ -571,13 +586,16 @@ __device__ __forceinline__ void local_gradient(const Lane& L, const RC& c, const
     }
 }
 
-// gradient-side vector  [g_eff] + lam_q c_q + C' vec   per lane.  base: include g0 and the local-variable terms.
+struct LG { double s, v, a0, a1; };     // local_gradient() of the current state (computed once per pass)
+
+// gradient-side vector  [g_eff] + lam_q c_q + C' vec   per lane.  lg != NULL: include g0 and the local-variable terms.
 template <int MMAX, int NS>
-__device__ __forceinline__ double gradient_side(const Lane& L, const RC& c, FMem<MMAX, NS>& M, int m, bool base, const double* vec,
+__device__ __forceinline__ double gradient_side(const Lane& L, const RC& c, FMem<MMAX, NS>& M, int m, const LG* lg, const double* vec,
                                                 double lam_q, int kq, double qal, double qbe, double qga, double qde) {
     const int lane = L.lane, N = L.N;
+    const bool base = lg != nullptr;
     double s = 0.0, v = 0.0, a0 = 0.0, a1 = 0.0;
-    if (base) local_gradient<NS>(L, c, M.ba, s, v, a0, a1);
+    if (base) { s = lg->s; v = lg->v; a0 = lg->a0; a1 = lg->a1; }
     if (lane <= N) { M.ws[lane] = s; M.wv[lane] = v; M.wa[lane] = a0; }
     WSYNC();
     if (lane > 0 && lane < N && a1 != 0.0) atomicAdd(&M.wa[lane - 1], a1);
@@ -624,9 +642,9 @@ __device__ __forceinline__ void solve_multipliers(FMem<MMAX, NS>& M, int m, int 
 struct Incoming { int kq, qcode, tq, gq; bool is_bound; double al, be, ga, de, d; };
 
 template <int MMAX, int NS>
-__device__ __forceinline__ void primal_from_multipliers(Lane& L, const RC& c, FMem<MMAX, NS>& M, const double* Hs, int m,
+__device__ __forceinline__ void primal_from_multipliers(Lane& L, const RC& c, FMem<MMAX, NS>& M, const double* Hs, int m, const LG& lg,
                                                         double lam_q, const Incoming& q, double& grad_total) {
-    const double g = gradient_side(L, c, M, m, true, M.lam, lam_q, q.kq, q.al, q.be, q.ga, q.de);
+    const double g = gradient_side(L, c, M, m, &lg, M.lam, lam_q, q.kq, q.al, q.be, q.ga, q.de);
     grad_total = g;
     if (L.lane < NS) M.yv[L.lane] = g;
     WSYNC();
@@ -639,9 +657,9 @@ __device__ __forceinline__ void primal_from_multipliers(Lane& L, const RC& c, FM
 }
 
 template <int MMAX, int NS>
-__device__ __forceinline__ double refine_primal(Lane& L, const RC& c, FMem<MMAX, NS>& M, const double* Hs, int m,
+__device__ __forceinline__ double refine_primal(Lane& L, const RC& c, FMem<MMAX, NS>& M, const double* Hs, int m, const LG& lg,
                                                 double lam_q, const Incoming& q, double& grad_total, int max_rounds, double res_tol) {
-    primal_from_multipliers(L, c, M, Hs, m, lam_q, q, grad_total);
+    primal_from_multipliers(L, c, M, Hs, m, lg, lam_q, q, grad_total);
     if (m == 0) return 0.0;
     double rel0 = 0.0;
     for (int round = 0; round < max_rounds; ++round) {
@@ -662,7 +680,7 @@ __device__ __forceinline__ double refine_primal(Lane& L, const RC& c, FMem<MMAX,
             M.lam[L.lane] += acc;
         }
         WSYNC();
-        primal_from_multipliers(L, c, M, Hs, m, lam_q, q, grad_total);
+        primal_from_multipliers(L, c, M, Hs, m, lg, lam_q, q, grad_total);
     }
     return rel0;
 }
@@ -698,9 +716,7 @@ __device__ __forceinline__ LocalMults local_mults(const Lane& L, const RC& c, co
 __device__ __forceinline__ bool w_relevant(const Lane& L, const RC& c, const Incoming* q, bool have_q) {
     if (L.lane >= L.N) return false;
     if (wpivot_of(L) >= 0) return true;
-    bool r = false;
-#pragma unroll
-    for (int t = F_FMLO; t <= F_RTHI; ++t) r = r || code_of(L, t) == 1 || code_of(L, t) == 2;
+    bool r = ((codes_eq1(L.code) | codes_eq2(L.code)) & type_range(F_FMLO, F_RTHI)) != 0ull;
     if (have_q && q->kq == L.lane && !q->is_bound && is_wrow(q->tq)) r = true;
     return r;
 }
@@ -766,9 +782,7 @@ __device__ __forceinline__ int warm_repair(Lane& L, const RC& c, const FMem<MMAX
             const int ek = fix >> 16;
             el = (fix >> 5) & 63; et = fix & 31;
             if (ek == EV_DROP) {
-                int pl = 0;
-#pragma unroll
-                for (int t = 0; t < kNumF; ++t) pl += (t < et && code_of(L, t) == 1) ? 1 : 0;
+                const int pl = __popcll(codes_eq1(L.code) & ((1ull << (2 * et)) - 1ull));
                 drop_pos = bcast_i(L.base + pl, el);
                 plain_drop = 1;
             }
@@ -805,7 +819,9 @@ __device__ __forceinline__ int find_violation(const Lane& L, const RC& c, const 
     // rows that w relaxes cost nothing to satisfy while the price of w is not positive (predicted speed below zero:
     // a transient of the dual iteration, v_k >= 0 is a hard row)
     const bool wfree = (lane < N) && !(c.c5 * (L.vbar + L.vh) + c.c2 > 0.0);
-    double myb = tolv; int myp = -1;
+    // scaled violation val / (1 + |b|): candidates are compared cross-multiplied (no division per row); bestv / bests is
+    // this lane's best so far, starting at the tolerance
+    double bestv = tolv, bests = 1.0; int myp = -1;
 #pragma unroll
     for (int t = 0; t < kNumF; ++t) {
         if (!((L.valid >> t) & 1u) || ((L.ign >> t) & 1u)) continue;
@@ -816,9 +832,10 @@ __device__ __forceinline__ int find_violation(const Lane& L, const RC& c, const 
         double val = row_al(t) * L.sh + row_be(t, c, L.chw) * L.vh + row_ga(t, c) * L.u + row_de(t, lane) * L.um1 - bt;
         if (lane < N) val += row_aw(t, c) * wv;
         val -= (g2 == GF) ? xiF : (g2 == GS ? xiS : (g2 == GV ? xiV : (g2 == GH ? xiH : 0.0)));
-        const double sc = val / (1.0 + fabs(bt));
-        if (sc > myb) { myb = sc; myp = t; }
+        const double sc = 1.0 + fabs(bt);
+        if (val * bests > bestv * sc) { bestv = val; bests = sc; myp = t; }
     }
+    double myb = bestv / bests;
     if (lane < N) {
         if (pivot_of(L, GF) >= 0 && !((L.ign >> (25 + GF)) & 1u) && L.lbF - xiF > myb) { myb = L.lbF - xiF; myp = 32 + GF; }
         if (pivot_of(L, GS) >= 0 && !((L.ign >> (25 + GS)) & 1u) && L.lbS - xiS > myb) { myb = L.lbS - xiS; myp = 32 + GS; }
@@ -869,6 +886,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
     FastInfo F{0, 0, 0, 0, 0, 1.0};
     int fast_run = 0;
     bool p_stale = false;
+    FT_DECL;
     for (;;) {
         if (F.fast != 0 && (++fast_run > 6 || p_stale)) F.fast = 0;
         p_stale = false;
@@ -876,6 +894,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         F.m_old = m;
         m = rebuild_and_factor(L, c, M, Hs, F);
         F.fast = 0;
+        FT_TOC(4);
         if (__any(L.unsup)) { st.status = 4; break; }
         if (m < 0) {
             if (!warm) { st.status = 2; break; }
@@ -888,8 +907,10 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             continue;
         }
         if (have_q) incoming_row<NS>(L, c, M.ba, q);
+        LG lg;
+        local_gradient<NS>(L, c, M.ba, lg.s, lg.v, lg.a0, lg.a1);
         if (m > 0) {
-            const double g = gradient_side(L, c, M, 0, true, nullptr, lam_q, q.kq, q.al, q.be, q.ga, q.de);
+            const double g = gradient_side(L, c, M, 0, &lg, nullptr, lam_q, q.kq, q.al, q.be, q.ga, q.de);
             if (lane < NS) M.yv[lane] = g;
             WSYNC();
             const double h = hinv_mul<NS>(Hs, M.yv, N, lane);
@@ -900,8 +921,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             WSYNC();
             solve_multipliers(M, m, lane, N);
         }
-        const double rel0 = refine_primal(L, c, M, Hs, m, lam_q, q, grad_total, 3, 1e-11);
+        const double rel0 = refine_primal(L, c, M, Hs, m, lg, lam_q, q, grad_total, 3, 1e-11);
         if (fast_run > 0 && rel0 > 1e-10) p_stale = true;
+        FT_TOC(5);
         if (warm) {
             const int rep = warm_repair(L, c, M, m, pass < kSinglePasses, F.drop_pos);
 #ifdef EEPACC_FBS_DEBUG
@@ -924,6 +946,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             const int relax_every = 3 * N + 30;
             const double tolv = kTolViol * (st.iters < relax_every ? 1.0 : (st.iters < 2 * relax_every ? 10.0 : (st.iters < 3 * relax_every ? 100.0 : 1000.0)));
             const int bp = find_violation<NS>(L, c, M.ba, tolv, best);
+            FT_TOC(6);
             if (bp < 0) break;
             if (++st.iters > max_iter) { st.status = 2; break; }
             q.kq = bp >> 6; q.qcode = bp & 63;
@@ -933,7 +956,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             have_q = true; lam_q = 0.0;
             incoming_row<NS>(L, c, M.ba, q);
         }
-        if (++st.events > 40 * max_iter) { st.status = 2; break; }
+        if (++st.events > 4 * max_iter) { st.status = 2; break; }
         const int kq = q.kq;
         double viol = q.al * M.shv[kq] + q.be * M.vhv[kq] - q.d;
         if (kq < N) viol += q.ga * M.av[kq];
@@ -974,7 +997,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         if (__any(wrel)) {
             double vz = vu;
             if (m > 0) {
-                const double gz = gradient_side(L, c, M, m, false, M.rv, 0.0, 0, 0.0, 0.0, 0.0, 0.0);
+                const double gz = gradient_side(L, c, M, m, nullptr, M.rv, 0.0, 0, 0.0, 0.0, 0.0, 0.0);
                 if (lane < NS) M.yv[lane] = gz;
                 WSYNC();
                 const double hz = hinv_mul<NS>(Hs, M.yv, N, lane);
@@ -1082,9 +1105,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         } else {
             const int ek = ev >> 16, el = (ev >> 5) & 63, et = ev & 31;
             if (ek == EV_DROP) {
-                int pl = 0;
-#pragma unroll
-                for (int t = 0; t < kNumF; ++t) pl += (t < et && code_of(L, t) == 1) ? 1 : 0;
+                const int pl = __popcll(codes_eq1(L.code) & ((1ull << (2 * et)) - 1ull));
                 F.drop_pos = bcast_i(L.base + pl, el);
                 F.fast = 2;
                 if (lane == el) set_code(L, et, 0);
@@ -1150,8 +1171,15 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             }
         }
         if (finished) { have_q = false; lam_q = 0.0; q.al = q.be = q.ga = q.de = q.d = 0.0; }
+        FT_TOC(7);
     }
-    if (st.status == 0 && m > 0) refine_primal(L, c, M, Hs, m, 0.0, q, grad_total, 4, 1e-14);
+    if (st.status == 0 && m > 0) {
+        LG lg;
+        local_gradient<NS>(L, c, M.ba, lg.s, lg.v, lg.a0, lg.a1);
+        refine_primal(L, c, M, Hs, m, lg, 0.0, q, grad_total, 4, 1e-14);
+    }
+    FT_TOC(8);
+    FT_FLUSH();
     st.m = m;
     return st;
 }
@@ -1179,6 +1207,7 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     const int lane = L.lane, N = C.N;
     const double lm = C.lambda * C.m, za = C.zeta_a;
     L.T = lane < N ? C.Tvec[lane] : 0.0;
+    FT_DECL;
     RC c;
     c.tau_min = C.tau_min;
     c.c1 = C.phi * C.T_m_max * C.T_m_max / 4.0 / C.P_m_max;
@@ -1318,30 +1347,36 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     if (lane < N) printf("DBG lane %d g0 %.15e Pi %.15e gam %.15e vbar %.15e H0 %.15e H5 %.15e Hd %.15e A22 %.15e D2 %.15e\n", lane, L.g0, L.Pi, L.gam, L.vbar,
                          Hs[0 * NS + lane], Hs[5 * NS + lane], Hs[lane * NS + lane], A22, D2);
 #endif
+    FT_TOC(0);
     // in-place inverse by symmetric sweeps (H is positive definite: cond ~ 1e2); afterwards Hs = -H^-1
     int h_bad = 0;
-    for (int k = 0; k < N; ++k) {
-        const double d = Hs[k * NS + k];
-        if (!(d > 0.0)) { h_bad = 1; break; }
-        const double inv = 1.0 / d;
-        if (lane < NS) M.colk[lane] = (lane < N) ? Hs[k * NS + lane] : 0.0;
-        WSYNC();
-        if (lane < NS) {
-            const double hkj = M.colk[lane];
-            double* col = Hs + lane;
-            if (lane == k) {
-#pragma unroll 4
-                for (int i = 0; i < NS; ++i) col[i * NS] = (i == k) ? -inv : M.colk[i] * inv;
-            } else {
-                const double f = hkj * inv;
-#pragma unroll 4
-                for (int i = 0; i < NS; ++i) col[i * NS] = (i == k) ? f : fma(-M.colk[i], f, col[i * NS]);
+    {
+        // all 64 lanes work: lane l updates rows [r0, r0 + RPL) of column l % NS (NS = 32: two lanes per column)
+        constexpr int HALVES = 64 / NS, RPL = NS / HALVES;
+        const int jcol = lane & (NS - 1), r0 = (lane / NS) * RPL;
+        double* col = Hs + jcol;
+        for (int k = 0; k < N; ++k) {
+            const double d = Hs[k * NS + k];
+            if (!(d > 0.0)) { h_bad = 1; break; }
+            const double inv = 1.0 / d;
+            if (lane < NS) M.colk[lane] = (lane < N) ? Hs[k * NS + lane] : 0.0;
+            WSYNC();
+            const double hkj = M.colk[jcol];
+            const double f = hkj * inv;
+            const bool piv = jcol == k;
+#pragma unroll
+            for (int ii = 0; ii < RPL; ++ii) {
+                const int i = r0 + ii;
+                const double ck = M.colk[i], old = col[i * NS];
+                const double upd = piv ? ck * inv : fma(-ck, f, old);
+                col[i * NS] = (i == k) ? (piv ? -inv : f) : upd;
             }
+            WSYNC();
         }
-        WSYNC();
     }
     for (int e = lane; e < NS * NS; e += 64) { const double x = -Hs[e]; Hs[e] = x; Hb[e] = x; }
     WSYNC();
+    FT_TOC(1);
     // rows: right-hand sides relative to the free response (CreateQP_FB.m:311-489)
     const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
     L.chw = C.FBuseTaylor ? T_hwp + 2.0 * G_hwp * v_est : T_hwp + G_hwp * v_est;
@@ -1407,7 +1442,13 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     WSYNC();
     double grad_total = 0.0;
     SolveStats st{2, 0, 0, 0};
-    if (!h_bad) st = solve_qp<MMAX, NS>(L, c, M, Hs, Hb, 16 * N + 100, grad_total);
+    FT_TOC(2);
+    FT_FLUSH();
+#ifdef EEPACC_FBS_TIMING
+    for (int _i = 0; _i < 16; ++_i) _fp[_i] = 0;
+#endif
+    // iteration cap: a cold solve needs about 1.5 N working-set changes; beyond 6 N + 60 the solve is cycling (status 1)
+    if (!h_bad) st = solve_qp<MMAX, NS>(L, c, M, Hs, Hb, 6 * N + 60, grad_total);
     code = L.code;
 #ifdef EEPACC_FBS_DEBUG
     if (lane <= N) printf("FIN lane %d code %llx u %.15e ign %x valid %x st %d iters %d m %d\n", lane, L.code, L.u, L.ign, L.valid, st.status, st.iters, st.m);
@@ -1454,6 +1495,10 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     so.out[EEPACC_OUT_AQP] = 0.0;
     if (st.status != 0) so.status = 1;
     so.iters = st.iters;
+#ifdef EEPACC_FBS_TIMING
+    _ft = wall_clock64() - 0;   // output phase is measured from the end of the solve by the caller's next step; negligible
+    if (lane == 0) atomicAdd(&g_fbs_prof[15], 1ull);
+#endif
 }
 
 // receding-horizon shift of the working set: stage k takes stage k+1's codes, the last stage and the terminal rows
@@ -1523,7 +1568,7 @@ k_fbs_step(fbs_step_args a) {
 // B1: closed loop over n_steps for B instances (ABO/RunOpt_FBMPC.m:161-331); work units (instance, chunk of MPC
 // steps) handed out through a device-wide counter as in the ABMPC kernel (eepacc_ab_impl.inc, k_run_abmpc)
 template <int MMAX, int NS, int WPB>
-__global__ void __launch_bounds__(64 * WPB)
+__global__ void __launch_bounds__(64 * WPB, (NS <= 32 ? 2 : 1))
 k_fbs_run(fbs_run_args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *a.cfg;
@@ -1631,6 +1676,15 @@ k_fbs_run(fbs_run_args a) {
 }
 
 }  // namespace fbs
+
+#ifdef EEPACC_FBS_TIMING
+extern "C" int eepacc_debug_fbs_prof(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fbs::g_fbs_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(fbs::g_fbs_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // host-side launchers used by eepacc_capi.cpp

@@ -57,6 +57,20 @@ size_t ab_smem_bytes(int N) {
     do { if (mb) EEPACC_LAUNCH_NS(withmb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);                           \
          else EEPACC_LAUNCH_NS(nomb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__); } while (0)
 
+// MPC steps per work unit of the closed-loop kernels: 16 (EEPACC_CHUNK overrides), fewer when the launch is so short
+// that the resident waves would otherwise get fewer than about eight units each (tail imbalance)
+int pick_chunk_steps(int n_steps, int B, int resident_waves) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* ev = getenv("EEPACC_CHUNK");
+        forced = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
+    }
+    if (forced > 0) return forced;
+    long long per = ((long long)n_steps * B) / (8LL * (resident_waves > 0 ? resident_waves : 1));
+    int c = per > kChunkStepsDefault ? kChunkStepsDefault : (int)per;
+    return c < 2 ? 2 : c;
+}
+
 hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
@@ -79,11 +93,7 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start
         e = hipMemsetAsync(iters_total, 0, sizeof(int32_t) * (size_t)B, stream);
         if (e != hipSuccess) return e;
     }
-    static int kChunkSteps = -1;
-    if (kChunkSteps < 0) {
-        const char* ev = getenv("EEPACC_CHUNK");
-        kChunkSteps = (ev && atoi(ev) > 0) ? atoi(ev) : kChunkStepsDefault;
-    }
+    const int kChunkSteps = pick_chunk_steps(n_steps, B, num_cus * (N > kNSSmall ? 2 : 8));
     // bound of the inter-unit spin wait (a debug hook lowers it to exercise the failure path)
     int spin_limit = 1 << 26;
     if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) spin_limit = atoi(ev);

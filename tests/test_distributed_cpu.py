@@ -1,9 +1,12 @@
-"""world_size-2 gloo test of the multi-GPU plumbing on CPU: the shards partition the scenario
-set exactly and the KPI all-reduce reproduces the single-process totals (the compute of each
-shard is done by the oracle here, tiny horizon, since there is no GPU in this container)."""
+"""world_size-2 gloo test of the multi-GPU job on CPU: bench.run_bench -- the same function the GPU ranks run, with
+its sharding, warm-up, timed loop, eepacc_postprocess energy and the SUM / MIN / MAX key-figure reductions -- is
+driven with a stand-in engine that computes each shard with the CPU oracle (there is no GPU in this container).
+The reduced key figures of the two ranks must equal those of one process running the union of the shards."""
+import json
 import os
 import sys
 import tempfile
+import types
 
 import numpy as np
 import pytest
@@ -13,54 +16,107 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 
+N_HOR, PER_RANK, K, W = 8, 2, 6, 2
+
+
+class OracleEngine:
+    """Engine stand-in with the interface bench.run_bench uses (run_abmpc / postprocess / last_iterations)."""
+
+    def __init__(self, OPT, V, dev, B):
+        from oracle import Oracle
+        self.orc = Oracle(OPT, V)
+        self.hist = None
+
+    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume=False, out=None):
+        from eepacc_mpc_casadi_matlab_amd._abi import OUT_N
+        s_tv = s_tv.numpy(); v_tv = v_tv.numpy()
+        self.hist = (s_tv, v_tv) if not resume else (np.concatenate([self.hist[0], s_tv]), np.concatenate([self.hist[1], v_tv]))
+        n_all, B = self.hist[0].shape
+        n = s_tv.shape[0]
+        traj, status = out
+        for i in range(B):
+            tr, st, _ = self.orc.run("ab", n_all, float(s0[i]), float(v0[i]), float(a_minus1[i]),
+                                     self.hist[0][:, i].copy(), self.hist[1][:, i].copy())
+            traj[:n, :, i] = torch.from_numpy(tr[n_all - n:])
+            status[:n, i] = torch.from_numpy(st[n_all - n:].astype(np.int32))
+        return traj[:n], status[:n]
+
+    def postprocess(self, traj):
+        from eepacc_mpc_casadi_matlab_amd._abi import OUT
+        n, _, B = traj.shape
+        outs = [torch.zeros((n, B), dtype=torch.float64) for _ in range(4)]
+        for i in range(B):
+            r = self.orc.postprocess(traj[:, OUT["v"], i].numpy().copy(), traj[:, OUT["Fm"], i].numpy().copy())
+            for o, x in zip(outs, r):
+                o[:, i] = torch.from_numpy(x)
+        return outs
+
+    def last_iterations(self, B):
+        return np.zeros(B, dtype=np.int32)
+
+
+def _args(batch):
+    return types.SimpleNamespace(workload="abmpc", steps=K, warmup=W, batch=batch, horizon=N_HOR, chunk=4,
+                                 no_cpu_baseline=True, gpus=1)
+
 
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from conftest import make_case
-    from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
-    from eepacc_mpc_casadi_matlab_amd.distributed import shard_range, reduce_kpis, max_over_ranks
-    from eepacc_mpc_casadi_matlab_amd._abi import OUT
-    from oracle import Oracle
-    OPT, V, _, _ = make_case("ABO", 8)
-    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
-    per_rank, n_steps = 2, 6
-    lo, hi = shard_range(rank, world, per_rank)
-    sc = make_s2(per_rank, n_steps, lead["V_TO_2Hz"], first_instance=lo)
-    orc = Oracle(OPT, V)
-    kpi = torch.zeros(3, dtype=torch.float64)
-    for i in range(per_rank):
-        traj, st, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
-        kpi += torch.tensor([float(st.sum()), traj[-1, OUT["s"]], float((traj[:, OUT["a"]] ** 2).sum())])
-    reduce_kpis(kpi, world)
-    tmax = max_over_ranks(float(rank + 1), world)
-    np.save(os.path.join(outdir, f"kpi_{rank}.npy"), np.concatenate([kpi.numpy(), [tmax], sc["v0"]]))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    res = bench.run_bench(_args(PER_RANK), make_engine=OracleEngine, device=torch.device("cpu"), backend="gloo")
+    if rank == 0:
+        assert res is not None
+        json.dump(res, open(os.path.join(outdir, "res.json"), "w"))
+    else:
+        assert res is None
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharding_and_kpi_reduction():
+def test_two_rank_job_equals_single_process():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
-        r0 = np.load(os.path.join(d, "kpi_0.npy")); r1 = np.load(os.path.join(d, "kpi_1.npy"))
-    assert np.array_equal(r0[:4], r1[:4])            # every rank holds the reduced KPIs
-    assert r0[3] == 2.0                              # MAX over ranks
-    # single-process reference over the union of the shards
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import make_case
-    from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
-    from eepacc_mpc_casadi_matlab_amd._abi import OUT
-    from oracle import Oracle
-    OPT, V, _, _ = make_case("ABO", 8)
-    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
-    sc = make_s2(4, 6, lead["V_TO_2Hz"])
-    np.testing.assert_array_equal(np.concatenate([r0[4:], r1[4:]]), sc["v0"])   # shards partition the set
-    orc = Oracle(OPT, V)
-    tot = np.zeros(3)
-    for i in range(4):
-        traj, st, _ = orc.run("ab", 6, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
-        tot += [st.sum(), traj[-1, OUT["s"]], (traj[:, OUT["a"]] ** 2).sum()]
-    np.testing.assert_allclose(r0[:3], tot, rtol=1e-12)
+        two = json.load(open(os.path.join(d, "res.json")))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    import bench
+    one = bench.run_bench(_args(2 * PER_RANK), make_engine=OracleEngine, device=torch.device("cpu"), backend="gloo")
+    assert two["ranks"] == 2 and one["ranks"] == 1
+    assert two["config"]["batch_per_gpu"] == PER_RANK and two["steps"] == K and two["scaling"] == "weak"
+    k2, k1 = two["kpi"], one["kpi"]
+    assert k2["instances"] == k1["instances"] == 2 * PER_RANK and k2["samples"] == k1["samples"] == 2 * PER_RANK * K
+    assert k2["bad_exits"] == k1["bad_exits"] == two["solver"]["bad_exits"]
+    for f in ("distance_km", "energy_kWh", "a_rms", "j_rms", "a_min", "a_max", "j_min", "j_max"):
+        assert k2[f] == pytest.approx(k1[f], rel=1e-12, abs=1e-15), f
+    assert k2["energy_kWh"] != 0.0 and k2["distance_km"] > 0.0
+    assert k2["a_max"] >= k2["a_min"] and k2["j_max"] >= k2["j_min"]
+
+
+def test_local_kpis_against_report():
+    """local_kpis / kpi_dict (the reduction's inputs) reproduce the single-vehicle key figures of report.kpi_report
+    (Main.m:203-263) on the saved ABMPC solution."""
+    from conftest import load_golden, make_case
+    from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
+    from eepacc_mpc_casadi_matlab_amd.distributed import local_kpis, kpi_dict
+    G = load_golden("abo_abmpc")
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    n = G["s_opt"].size
+    traj = torch.zeros((n, OUT_N, 1), dtype=torch.float64)
+    for nm in ("s", "v", "a", "Fm", "Fb"):
+        traj[:, OUT[nm], 0] = torch.from_numpy(np.asarray(G[nm + "_opt"], dtype=np.float64).ravel())
+    status = torch.from_numpy(np.asarray(G["exitMessage"]).ravel().astype(np.int32)).reshape(n, 1)
+    E = torch.from_numpy(np.asarray(G["E_opt"], dtype=np.float64).ravel()).reshape(n, 1)
+    k = kpi_dict(*local_kpis(traj, status, E, 0.5, 1000.0, OUT))
+    assert k["bad_exits"] == 0 and k["instances"] == 1 and k["samples"] == n
+    assert k["distance_km"] == pytest.approx(G["s_opt"][-1] / 1e3, rel=1e-12)
+    assert k["energy_kWh"] == pytest.approx(G["E_opt"][-1] / 3.6e6, rel=1e-12)            # 2592661.34 J (SURVEY 8c)
+    a = np.asarray(G["a_opt"]).ravel(); j = np.asarray(G["j_opt"]).ravel()
+    assert k["a_max"] == pytest.approx(a.max()) and k["a_min"] == pytest.approx(a.min())
+    assert k["j_max"] == pytest.approx(j.max()) and k["j_min"] == pytest.approx(j.min())
+    assert k["a_rms"] == pytest.approx(np.sqrt(np.mean(a * a)), rel=1e-12)
+    assert k["j_rms"] == pytest.approx(np.sqrt(np.mean(j * j)), rel=1e-12)
+    i_cut = int(np.argmax(np.asarray(G["s_opt"]).ravel() >= 1000.0))
+    assert k["instances_reaching_cutoff"] == 1 and k["mean_travel_time_at_cutoff_s"] == pytest.approx(i_cut * 0.5)
