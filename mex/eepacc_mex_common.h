@@ -1,0 +1,261 @@
+/*
+ * eepacc_mex_common.h -- shared part of the MEX gateways RunOpt_ABMPC.c / RunOpt_FBMPC.c.
+ *
+ * A compiled RunOpt_ABMPC.mexa64 / RunOpt_FBMPC.mexa64 placed next to Main.m shadows the .m file of the same
+ * name, so `optSol = RunOpt_ABMPC(OPTsettings)` (ABO/Main.m:115, ABO/RunOpt_ABMPC.m:1) and
+ * `optSol = RunOpt_FBMPC(OPTsettings)` (ABO/Main.m:106, ABO/RunOpt_FBMPC.m:1) run on the GPU through libeepacc
+ * (include/eepacc.h) without any change to the harness.
+ *
+ * Contract (level B1):
+ *   in : the OPTsettings struct; every field the reference reads on this path is read by name
+ *        (ABO/RunOpt_ABMPC.m:17-30, CreateQP_AB.m:27-34, CreateQP_FB.m:30-39,
+ *        EstimateRouteAndComfortBounds.m:25-39, EstimateVehicleTrajectory.m:32-46, RunPlantModel.m:17);
+ *        the vehicle struct comes from the tree's own SetVehicleParameters() (called through MATLAB, as every
+ *        reference function does, e.g. CreateQP_AB.m:37), so ABO/ and ORIG/ get their own constants.
+ *   out: the optSol struct with the fields of ABO/RunOpt_ABMPC.m:354-404 (FB: ABO/RunOpt_FBMPC.m:345-397).
+ *   errors: a QP that fails is NOT an error -- exitMessage(k) = 1 and the iterate is applied
+ *        (opts.error_on_fail = false, ABO/RunOpt_ABMPC.m:121,255).  mexErrMsgIdAndTxt only for malformed input or
+ *        a device failure.
+ *
+ * Build (on a machine with MATLAB and ROCm; neither the build container nor the GPU box of this repository has
+ * MATLAB, so these files are a source deliverable that is compiled against a stub mex.h in CI, see
+ * tests/test_mex_sources.py):
+ *     mex -I../include RunOpt_ABMPC.c -L../eepacc_mpc_casadi_matlab_amd -leepacc
+ *     mex -I../include RunOpt_FBMPC.c -L../eepacc_mpc_casadi_matlab_amd -leepacc
+ */
+#ifndef EEPACC_MEX_COMMON_H
+#define EEPACC_MEX_COMMON_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "mex.h"
+#include "eepacc.h"
+
+#define EEPACC_PI 3.14159265358979323846
+
+typedef struct eepacc_mex_inputs {
+    eepacc_settings S;
+    eepacc_vehicle V;
+    int32_t* Mb;          /* mxMalloc'd */
+    double* TLLoc;        /* mxMalloc'd, row-major [n_TL][4] */
+    int n_steps;          /* N_sim + 1 */
+    double Ts;
+    const double *s_tv, *v_tv;
+    double s_init, v_init, a_minus1;
+    double W[7];          /* the controller's weight vector as given (for the cost_* series) */
+    int nW;
+} eepacc_mex_inputs;
+
+static const mxArray* emx_field(const mxArray* S, const char* name, int required) {
+    const mxArray* f = mxGetField(S, 0, name);
+    if (!f && required) mexErrMsgIdAndTxt("eepacc:missingField", "OPTsettings.%s is missing", name);
+    return f;
+}
+static double emx_scalar(const mxArray* S, const char* name) {
+    const mxArray* f = emx_field(S, name, 1);
+    if (mxIsEmpty(f) || !(mxIsDouble(f) || mxIsLogical(f)))
+        mexErrMsgIdAndTxt("eepacc:badField", "OPTsettings.%s must be a real scalar", name);
+    return mxGetScalar(f);
+}
+static double emx_scalar_opt(const mxArray* S, const char* name, double dflt) {
+    const mxArray* f = mxGetField(S, 0, name);
+    return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
+}
+static const double* emx_vector(const mxArray* S, const char* name, int* len, int required) {
+    const mxArray* f = emx_field(S, name, required);
+    if (!f || mxIsEmpty(f)) { *len = 0; return NULL; }
+    if (!mxIsDouble(f) || mxIsComplex(f)) mexErrMsgIdAndTxt("eepacc:badField", "OPTsettings.%s must be a real double array", name);
+    *len = (int)mxGetNumberOfElements(f);
+    return mxGetPr(f);
+}
+
+/* V = SetVehicleParameters()  (ABO/Functions/Settings/SetVehicleParameters.m:12-133) */
+static void emx_vehicle(eepacc_vehicle* V) {
+    mxArray* out = NULL;
+    if (mexCallMATLAB(1, &out, 0, NULL, "SetVehicleParameters") != 0 || !out || !mxIsStruct(out))
+        mexErrMsgIdAndTxt("eepacc:vehicle", "SetVehicleParameters() did not return a struct");
+    memset(V, 0, sizeof *V);
+#define EMX_V(field, req) do { const mxArray* f_ = mxGetField(out, 0, #field); \
+        if (f_) V->field = mxGetScalar(f_); else if (req) mexErrMsgIdAndTxt("eepacc:vehicle", "V." #field " is missing"); } while (0)
+    EMX_V(m, 1); EMX_V(A_f, 1); EMX_V(c_d, 1); EMX_V(L, 1); EMX_V(h_g, 1); EMX_V(WD_s_F, 0); EMX_V(L_f, 1); EMX_V(L_r, 0);
+    EMX_V(F0, 0); EMX_V(F1, 0); EMX_V(F2, 0); EMX_V(p00, 0); EMX_V(p10, 0); EMX_V(p01, 0);     /* ABO only */
+    EMX_V(P_m_max, 1); EMX_V(T_m_max, 1); EMX_V(omega_m_r, 1); EMX_V(omega_m_max, 0);
+    EMX_V(c_r, 1); EMX_V(R_w, 0); EMX_V(beta_gb, 0); EMX_V(beta_fd, 0); EMX_V(phi, 1);
+    EMX_V(v_max, 1); EMX_V(eta_TF, 1); EMX_V(mu, 1); EMX_V(rho_a, 0); EMX_V(g, 1); EMX_V(zeta_a, 1);
+#undef EMX_V
+    { const mxArray* f_ = mxGetField(out, 0, "lambda");
+      if (!f_) mexErrMsgIdAndTxt("eepacc:vehicle", "V.lambda is missing");
+      V->lambda = mxGetScalar(f_); }
+    mxDestroyArray(out);
+}
+
+/* read every OPTsettings field of the path into the PODs of include/eepacc.h.  fb: FBMPC (W_FB) or ABMPC (W_AB) */
+static void emx_read_inputs(const mxArray* O, int fb, eepacc_mex_inputs* in) {
+    int n, n2;
+    memset(in, 0, sizeof *in);
+    eepacc_settings* S = &in->S;
+    S->N_hor = (int)emx_scalar(O, "N_hor");
+    if (S->N_hor < 2 || S->N_hor > EEPACC_MAX_HORIZON) mexErrMsgIdAndTxt("eepacc:badField", "N_hor must be in [2, %d]", EEPACC_MAX_HORIZON);
+    S->Tvec = emx_vector(O, "Tvec", &n, 1);                                   /* RunOpt_ABMPC.m:22 */
+    if (n != S->N_hor) mexErrMsgIdAndTxt("eepacc:badField", "numel(Tvec) must equal N_hor");
+    {   /* Mb (Settings.m:243-250): double in MATLAB, int32 in the C-ABI */
+        const double* mb = emx_vector(O, "Mb", &n, 0);
+        in->Mb = (int32_t*)mxCalloc((size_t)S->N_hor, sizeof(int32_t));
+        if (mb) {
+            if (n != S->N_hor) mexErrMsgIdAndTxt("eepacc:badField", "numel(Mb) must equal N_hor");
+            for (int i = 0; i < n; ++i) in->Mb[i] = mb[i] != 0.0;
+        }
+        S->Mb = in->Mb;
+    }
+    {   /* weights: ABO W_AB has 7 entries (w_FC first), ORIG 6 (Settings.m:48-64); W_FB always 7 (:31-46) */
+        const double* W = emx_vector(O, "W_AB", &n, !fb);
+        if (W) {
+            if (n != 6 && n != 7) mexErrMsgIdAndTxt("eepacc:badField", "W_AB must have 6 (ORIG) or 7 (ABO) entries");
+            S->ab_fuel_term = (n == 7);
+            S->ab_route_rows = (n == 6);           /* ORIG keeps the speed-limit / curve / stop / TL rows (CreateQP_AB.m:324-346) */
+            for (int i = 0; i < 7; ++i) S->W_AB[i] = (n == 7) ? W[i] : (i ? W[i - 1] : 0.0);
+            if (!fb) { in->nW = n; memcpy(in->W, W, sizeof(double) * (size_t)n); }
+        } else {
+            for (int i = 1; i < 7; ++i) S->W_AB[i] = 1.0;      /* unused by FBMPC; keep eepacc_create's checks satisfied */
+        }
+        const double* Wf = emx_vector(O, "W_FB", &n2, fb);
+        if (Wf) {
+            if (n2 != 7) mexErrMsgIdAndTxt("eepacc:badField", "W_FB must have 7 entries");
+            memcpy(S->W_FB, Wf, sizeof(double) * 7);
+            if (fb) { in->nW = 7; memcpy(in->W, Wf, sizeof(double) * 7); }
+        }
+    }
+    S->tau_min = emx_scalar(O, "tau_min"); S->h_min = emx_scalar(O, "h_min"); S->s_goal = emx_scalar(O, "s_goal");
+    S->paramEstSetting = (int)emx_scalar(O, "paramEstSetting"); S->TVestSetting = (int)emx_scalar(O, "TVestSetting");
+    S->tConstACC_ego = emx_scalar(O, "tConstACC_ego"); S->tConstACC_tar = emx_scalar(O, "tConstACC_tar");
+    S->N_integratePlant = (int)emx_scalar(O, "N_integratePlant");
+    S->solverToUse = (int)emx_scalar(O, "solverToUse");
+    S->FBuseTaylor = (int)emx_scalar_opt(O, "FBuseTaylor", 1.0);
+    {
+        const double* b = emx_vector(O, "b_quadr", &n, fb);
+        if (b) { if (n != 6) mexErrMsgIdAndTxt("eepacc:badField", "b_quadr must have 6 entries"); memcpy(S->b_quadr, b, sizeof(double) * 6); }
+        b = emx_vector(O, "b_fifthOrder", &n, 1);
+        if (n != 21) mexErrMsgIdAndTxt("eepacc:badField", "b_fifthOrder must have 21 entries");
+        memcpy(S->b_fifthOrder, b, sizeof(double) * 21);
+    }
+    /* route tables written by GenerateUseCase (GenerateUseCase.m:50-116) */
+    S->s_speedLim = emx_vector(O, "s_speedLim", &n, 1); S->v_speedLim = emx_vector(O, "v_speedLim", &n2, 1);
+    if (n != n2) mexErrMsgIdAndTxt("eepacc:badField", "s_speedLim and v_speedLim differ in length");
+    S->n_speedLim = n;
+    S->s_curv = emx_vector(O, "s_curv", &n, 1); S->curvature = emx_vector(O, "curvature", &n2, 1);
+    if (n != n2) mexErrMsgIdAndTxt("eepacc:badField", "s_curv and curvature differ in length");
+    S->n_curv = n;
+    S->s_slope = emx_vector(O, "s_slope", &n, 1); S->slope = emx_vector(O, "slope", &n2, 1);
+    if (n != n2) mexErrMsgIdAndTxt("eepacc:badField", "s_slope and slope differ in length");
+    S->n_slope = n;
+    S->stopLoc = emx_vector(O, "stopLoc", &n, 0); S->n_stop = n;
+    {   /* TLLoc: n_TL x 4 [location, phase, red, green], column-major in MATLAB -> row-major */
+        const mxArray* f = mxGetField(O, 0, "TLLoc");
+        if (f && !mxIsEmpty(f)) {
+            if (mxGetN(f) != 4) mexErrMsgIdAndTxt("eepacc:badField", "TLLoc must be n x 4");
+            const int r = (int)mxGetM(f);
+            const double* p = mxGetPr(f);
+            in->TLLoc = (double*)mxMalloc(sizeof(double) * 4 * (size_t)r);
+            for (int i = 0; i < r; ++i) for (int j = 0; j < 4; ++j) in->TLLoc[4 * i + j] = p[(size_t)j * r + i];
+            S->TLLoc = in->TLLoc; S->n_TL = r;
+        }
+    }
+    S->stopRefDist = emx_scalar(O, "stopRefDist"); S->stopRefVelSlope = emx_scalar(O, "stopRefVelSlope");
+    S->stopVel = emx_scalar(O, "stopVel"); S->TLstopVel = emx_scalar(O, "TLstopVel");
+    S->TLStopRegionSize = emx_scalar(O, "TLStopRegionSize"); S->alpha_TTL = emx_scalar(O, "alpha_TTL");
+    /* simulation (RunOpt_ABMPC.m:24-30, 33-34) */
+    in->Ts = S->Tvec[0];
+    in->n_steps = (int)floor(emx_scalar(O, "t_sim") / in->Ts + 0.5) + 1;      /* kk = 0:N_sim (:154) */
+    in->s_init = emx_scalar(O, "s_init"); in->v_init = emx_scalar(O, "v_init"); in->a_minus1 = emx_scalar(O, "a_minus1");
+    in->s_tv = emx_vector(O, "s_tv", &n, 1); in->v_tv = emx_vector(O, "v_tv", &n2, 1);
+    if (n < in->n_steps || n2 < in->n_steps)
+        mexErrMsgIdAndTxt("eepacc:badField", "s_tv / v_tv must hold t_sim/Ts + 1 = %d samples", in->n_steps);
+    emx_vehicle(&in->V);
+}
+
+/* Functions/Other/GetMotorPower_FifthOrderSurface.m:16-20 */
+static double emx_power(double x, double y, const double* b) {
+    const double x2 = x * x, x3 = x2 * x, x4 = x3 * x, x5 = x4 * x, y2 = y * y, y3 = y2 * y, y4 = y3 * y, y5 = y4 * y;
+    return b[0] + b[1] * x + b[2] * y + b[3] * x2 + b[4] * x * y + b[5] * y2 + b[6] * x3 + b[7] * x2 * y + b[8] * x * y2 + b[9] * y3 +
+           b[10] * x4 + b[11] * x3 * y + b[12] * x2 * y2 + b[13] * x * y3 + b[14] * y4 + b[15] * x5 + b[16] * x4 * y + b[17] * x3 * y2 +
+           b[18] * x2 * y3 + b[19] * x * y4 + b[20] * y5;
+}
+
+static mxArray* emx_col(int n) { return mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); }
+static void emx_set(mxArray* S, const char* name, mxArray* v) {
+    if (mxGetFieldNumber(S, name) < 0) mxAddField(S, name);
+    mxSetField(S, 0, name, v);
+}
+
+/* Build optSol from the trajectory block traj[n][EEPACC_OUT_N] and status[n] (B = 1).
+ * cost_names / cost_w / cost_src: the cumulative cost series of the controller (RunOpt_ABMPC.m:383-404,
+ * RunOpt_FBMPC.m:373-397); src 0..6 = P^2, a^2, j^2, xi_v, xi_h, xi_s, xi_f. */
+static mxArray* emx_build_optsol(const eepacc_mex_inputs* in, const double* traj, const int32_t* status, double wall_s,
+                                 int n_cost, const char* const* cost_names, const double* cost_w, const int* cost_src) {
+    const int n = in->n_steps, N_sim = n - 1;
+    const eepacc_vehicle* V = &in->V;
+    mxArray* sol = mxCreateStructMatrix(1, 1, 0, NULL);
+    static const char* names[] = {"s_opt", "v_opt", "Fm_opt", "Fb_opt", "a_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt"};
+    static const int idx[] = {EEPACC_OUT_S, EEPACC_OUT_V, EEPACC_OUT_FM, EEPACC_OUT_FB, EEPACC_OUT_A,
+                              EEPACC_OUT_XI_V, EEPACC_OUT_XI_H, EEPACC_OUT_XI_S, EEPACC_OUT_XI_F};
+    double* col[9];
+    for (int f = 0; f < 9; ++f) {
+        mxArray* a = emx_col(n);
+        col[f] = mxGetPr(a);
+        for (int k = 0; k < n; ++k) col[f][k] = traj[(size_t)k * EEPACC_OUT_N + idx[f]];
+        emx_set(sol, names[f], a);
+    }
+    const double *v = col[1], *Fm = col[2], *a_opt = col[4];
+    /* derived quantities (RunOpt_ABMPC.m:343-349) */
+    mxArray *mrpm = emx_col(n), *mTm = emx_col(n), *mP = emx_col(n), *mE = emx_col(n), *mj = emx_col(N_sim);
+    double *rpm = mxGetPr(mrpm), *Tm = mxGetPr(mTm), *P = mxGetPr(mP), *E = mxGetPr(mE), *j = mxGetPr(mj);
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) {
+        rpm[k] = (30.0 / EEPACC_PI) * v[k] * V->phi;
+        const double sg = (Fm[k] > 0.0) - (Fm[k] < 0.0);
+        Tm[k] = Fm[k] / V->phi / pow(V->eta_TF, sg);
+        P[k] = emx_power(Fm[k], rpm[k], in->S.b_fifthOrder);
+        acc += P[k];
+        E[k] = in->Ts * acc;
+    }
+    for (int k = 0; k < N_sim; ++k) j[k] = (a_opt[k + 1] - a_opt[k]) / in->Ts;             /* :354 */
+    emx_set(sol, "P_opt", mP); emx_set(sol, "E_opt", mE); emx_set(sol, "j_opt", mj);
+    emx_set(sol, "Tm_opt", mTm); emx_set(sol, "rpm_opt", mrpm);
+    /* timing vectors: the whole closed loop runs in one kernel launch, so the wall time is spread evenly */
+    {
+        mxArray *tl = emx_col(n), *ts = emx_col(n), *st = mxCreateDoubleMatrix(1, (mwSize)n, mxREAL), *ex = mxCreateDoubleMatrix(1, (mwSize)n, mxREAL);
+        for (int k = 0; k < n; ++k) {
+            mxGetPr(tl)[k] = wall_s / n; mxGetPr(ts)[k] = wall_s / n; mxGetPr(st)[k] = wall_s / n;
+            mxGetPr(ex)[k] = status[k] != 0;                                                   /* :255 */
+        }
+        emx_set(sol, "tLoop", tl); emx_set(sol, "tSolve", ts); emx_set(sol, "solverTime", st); emx_set(sol, "exitMessage", ex);
+    }
+    /* the dense H, G of the last step (:377-378) are never formed by the fused kernels */
+    emx_set(sol, "H", mxCreateDoubleMatrix(0, 0, mxREAL)); emx_set(sol, "G", mxCreateDoubleMatrix(0, 0, mxREAL));
+    {
+        mxArray *dh = emx_col(n), *co = emx_col(n);
+        for (int k = 0; k < n; ++k) { mxGetPr(dh)[k] = traj[(size_t)k * EEPACC_OUT_N + EEPACC_OUT_DISTHOR]; mxGetPr(co)[k] = traj[(size_t)k * EEPACC_OUT_N + EEPACC_OUT_COST]; }
+        emx_set(sol, "DistHor", dh); emx_set(sol, "cost", co);
+    }
+    /* cumulative costs over the horizon, k = 1..N_sim */
+    for (int c = 0; c < n_cost; ++c) {
+        mxArray* a = emx_col(N_sim);
+        double* o = mxGetPr(a); double sacc = 0.0;
+        for (int k = 0; k < N_sim; ++k) {
+            double x;
+            switch (cost_src[c]) {
+                case 0: x = P[k] * P[k]; break;
+                case 1: x = a_opt[k] * a_opt[k]; break;
+                case 2: x = j[k] * j[k]; break;
+                default: x = col[5 + (cost_src[c] - 3)][k]; break;     /* xi_v, xi_h, xi_s, xi_f */
+            }
+            sacc += x;
+            o[k] = cost_w[c] * sacc;
+        }
+        emx_set(sol, cost_names[c], a);
+    }
+    return sol;
+}
+
+#endif /* EEPACC_MEX_COMMON_H */

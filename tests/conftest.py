@@ -20,6 +20,19 @@ def lead_trace():
     return np.load(os.path.join(GOLDEN, "lead_TO01_EAD.npz"))
 
 
+# Saved ABMPC solutions of the ABO tree written with other weight sets than the checked-in Settings.m (its commented
+# alternatives, ABO/Settings.m:48-64: w_FC % 50, w_c % 0.1, w_v % 8e5, w_h % 1e4, w_f % 1e10, W_AB = 1e-3*W).  The
+# reference does not store OPTsettings with a solution; the weights below are recovered from the files themselves:
+# W(1..4) from the cost_* series (cost_a = W(1) cumsum(a^2), ... -- the index shift of RunOpt_ABMPC.m:381-388), w_h
+# from the xi_h diagonal of the saved H (2 w_h), w_FC p01 F2 from H(1,1); w_s, w_f from the comments (w_f = 1e-3 * 1e10,
+# w_s = 9 w_f) -- EFFMAP has xi_s, xi_f > 0 and matches with them.  Vehicle constants: the checked-in ones.
+GOLDEN_AB_VARIANTS = {
+    "abo_abmpc_effmap":  [1000.0, 30.0, 1000.0, 800.0, 0.1, 9e7, 1e7],
+    "abo_abmpc_fcopt":   [0.05, 30.0, 1000.0, 800.0, 10.0, 9e7, 1e7],
+    "abo_abmpc_nofcopt": [0.0, 3.0, 100.0, 800.0, 10.0, 9e7, 1e7],
+}
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -1,0 +1,48 @@
+"""The MEX gateways mex/RunOpt_ABMPC.c and mex/RunOpt_FBMPC.c (level B1) are a source
+deliverable: MATLAB exists neither here nor on the GPU box.  What can be checked without it: they are complete,
+warning-free C against the MEX API's signatures (tests/mexstub/mex.h holds declarations only), they bind exactly
+the host entry points of include/eepacc.h, read every OPTsettings field the reference reads on this path and write
+every optSol field the reference returns."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+MEX = os.path.join(ROOT, "mex")
+
+
+@pytest.mark.parametrize("src", ["RunOpt_ABMPC.c", "RunOpt_FBMPC.c"])
+def test_gateway_compiles_against_the_mex_api(src, tmp_path):
+    obj = tmp_path / (src + ".o")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-c", os.path.join(MEX, src), "-o", str(obj),
+           "-I", os.path.join(ROOT, "tests", "mexstub"), "-I", os.path.join(ROOT, "include")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True).stdout
+    entry = "eepacc_run_abmpc_host" if "AB" in src else "eepacc_run_fbmpc_host"
+    for need in ("eepacc_create", "eepacc_destroy", "eepacc_last_error", entry, "mexCallMATLAB", "mexErrMsgIdAndTxt"):
+        assert re.search(r"\b%s\b" % need, syms), need
+    assert "mexFunction" in subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout
+
+
+def test_gateway_reads_and_writes_the_reference_fields():
+    common = open(os.path.join(MEX, "eepacc_mex_common.h")).read()
+    read = set(re.findall(r'emx_(?:scalar|scalar_opt|vector)\(O, "(\w+)"', common)) | set(re.findall(r'mxGetField\(O, 0, "(\w+)"\)', common))
+    # OPTsettings fields read on this path
+    need = {"N_hor", "Tvec", "Mb", "W_AB", "W_FB", "t_sim", "s_init", "v_init", "a_minus1", "s_tv", "v_tv", "solverToUse",
+            "FBuseTaylor", "b_fifthOrder", "b_quadr", "tau_min", "h_min", "s_goal", "s_speedLim", "v_speedLim", "s_curv",
+            "curvature", "s_slope", "slope", "stopLoc", "stopRefDist", "stopRefVelSlope", "stopVel", "TLLoc", "TLstopVel",
+            "TLStopRegionSize", "alpha_TTL", "paramEstSetting", "TVestSetting", "tConstACC_ego", "tConstACC_tar",
+            "N_integratePlant"}
+    assert need <= read, need - read
+    written = set(re.findall(r'emx_set\(sol, "(\w+)"', common)) | set(re.findall(r'"(\w+_opt)"', common))
+    for src in ("RunOpt_ABMPC.c", "RunOpt_FBMPC.c"):
+        written |= set(re.findall(r'"(cost_\w+)"', open(os.path.join(MEX, src)).read()))
+    # optSol fields of ABO/RunOpt_ABMPC.m:354-404 and ABO/RunOpt_FBMPC.m:345-397
+    out = {"s_opt", "v_opt", "Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt", "P_opt", "E_opt", "a_opt",
+           "j_opt", "Tm_opt", "rpm_opt", "tLoop", "tSolve", "H", "G", "DistHor", "exitMessage", "solverTime",
+           "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f", "cost_P"}
+    assert out <= written, out - written

@@ -7,7 +7,7 @@ per-step QP outputs and the 871-step closed loop, post-processing.  CPU only.
 import numpy as np
 import pytest
 
-from conftest import load_golden, make_case, golden_step_inputs
+from conftest import load_golden, make_case, golden_step_inputs, GOLDEN_AB_VARIANTS
 from eepacc_mpc_casadi_matlab_amd._abi import OUT
 from oracle import Oracle
 from oracle.loader import LoopState
@@ -106,6 +106,27 @@ def test_lead_trace_matches_xi_h_rows():
     pred = G["s_opt"][k] + (T_hwp + G_hwp * v) * v - (s_tv[k] - A_hwp)
     assert len(k) > 200
     assert np.abs(pred - G["xi_h_opt"][k]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_AB_VARIANTS))
+def test_ab_weight_variants_closed_loop_and_H(name):
+    """The saved ABMPC solutions written with other weight sets (conftest.GOLDEN_AB_VARIANTS: weights recovered from
+    the files' own cost_* series and H): 871-step closed loop and the final-step dense H, G."""
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    OPT = dict(OPT); OPT["W_AB"] = np.array(GOLDEN_AB_VARIANTS[name])
+    G = load_golden(name)
+    orc = Oracle(OPT, V)
+    ref, st, _ = orc.run("ab", 871, 0.0, 0.0, 0.0, s_tv, v_tv)
+    assert st.sum() == 0 and G["exitMessage"].sum() == 0
+    for n, g, tol in (("s", "s_opt", 1e-10), ("v", "v_opt", 1e-10), ("xi_v", "xi_v_opt", 1e-10), ("xi_h", "xi_h_opt", 1e-10),
+                      ("xi_s", "xi_s_opt", 1e-10), ("xi_f", "xi_f_opt", 1e-10), ("Fm", "Fm_opt", 1e-6), ("Fb", "Fb_opt", 1e-6),
+                      ("a", "a_opt", 1e-10)):
+        assert np.abs(ref[:, OUT[n]] - G[g]).max() < tol, n          # measured: s 9e-12, Fm 6e-8 (EFFMAP)
+    rpm, Tm, P, E = orc.postprocess(ref[:, OUT["v"]], ref[:, OUT["Fm"]])
+    assert abs(E[-1] - G["E_opt"][-1]) < 1e-9 * abs(G["E_opt"][-1])
+    r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, 870), want_dense=True)
+    assert np.abs(r["G"] - G["G"]).max() <= 1e-13
+    assert np.abs(r["H"] - G["H"]).max() <= 1e-12 * np.abs(G["H"]).max()
 
 
 @pytest.mark.parametrize("tree", TREES)

@@ -68,6 +68,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     extract(os.path.join(ABO, "savedABMPCsol.mat"), "ABMPCsol", "abo_abmpc.npz")
     extract(os.path.join(ABO, "savedFBMPCsol.mat"), "FBMPCsol", "abo_fbmpc.npz")
+    # ABMPC runs saved with other weight sets / fuel terms (the commented alternatives of ABO/Settings.m:48-64); the
+    # weights are recovered in tests/conftest.py (GOLDEN_AB_VARIANTS) from the cost_* series and the final H.
+    # savedABMPCsolICEMAP.mat is not extracted: its fuel-map constants are not in the tree ("parity unpinned")
+    extract(os.path.join(ABO, "savedABMPCsolEFFMAP.mat"), "ABMPCsolEFFMAP", "abo_abmpc_effmap.npz")
+    extract(os.path.join(ABO, "savedABMPCsolFCopt.mat"), "ABMPCsolFCopt", "abo_abmpc_fcopt.npz")
+    extract(os.path.join(ABO, "savedABMPCsolnoFCopt.mat"), "ABMPCsolnoFCopt", "abo_abmpc_nofcopt.npz")
+    extract(os.path.join(ABO, "savedBLMPCsol.mat"), "BLMPCsol", "abo_blmpc.npz")
+    extract(os.path.join(ORIG, "savedBLMPCsol.mat"), "BLMPCsol", "orig_blmpc.npz")
     extract(os.path.join(ORIG, "savedABMPCsol.mat"), "ABMPCsol", "orig_abmpc.npz")
     extract(os.path.join(ORIG, "savedFBMPCsol.mat"), "FBMPCsol", "orig_fbmpc.npz")
     lead_trace()
