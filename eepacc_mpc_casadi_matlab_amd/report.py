@@ -73,3 +73,29 @@ def format_report(name: str, k: Dict[str, float], OPT: Dict[str, Any]) -> str:
         f"Comfort metrics at {cut:g} km:",
         f"   {name}: max. a = {k['a_max']:.5g}m/s2, min. a = {k['a_min']:.5g}m/s2, rms. a = {k['a_rms']:.5g}m/s2",
         f"   {name}: max. j = {k['j_max']:.5g}m/s3, min. j = {k['j_min']:.5g}m/s3, rms. j = {k['j_rms']:.5g}m/s3", ""])
+
+
+def fuel_economy(sol: Dict[str, Any], V: Dict[str, float], Ts: float = 0.5) -> Dict[str, Any]:
+    """Fuel consumption of a closed-loop run with the linear fuel map of the ABO tree (ABO/Custom_plots.m:73-107):
+    wheel torque TW = max(0, (lambda m a + F0 + F2 v^2) R_w), fuel flow FC = max(0.25, p00 + p10 v + p01 TW) [g/s],
+    cumulative fuel [kg] with the sample time Ts (0.5 s in the reference) and fuel economy [L/100 km] at a density of
+    0.835 kg/L.  sol: struct with a_opt, v_opt, s_opt (RunOpt_ABMPC / a saved solution)."""
+    a = np.asarray(sol["a_opt"], dtype=np.float64).ravel()
+    v = np.asarray(sol["v_opt"], dtype=np.float64).ravel()
+    s = np.asarray(sol["s_opt"], dtype=np.float64).ravel()
+    TW = np.maximum(0.0, (V["lambda"] * V["m"] * a + V["F0"] + V["F2"] * v * v) * V["R_w"])
+    FC = np.maximum(0.25, V["p00"] + V["p10"] * v + V["p01"] * TW)
+    TW[0] = 0.0; FC[0] = 0.0                        # the loop starts at i = 2 (:81): the first sample stays zero
+    FC_tot = np.cumsum(FC / 1000.0 * Ts)
+    return {"TW_opt": TW, "FC": FC, "FC_tot_kg": FC_tot,
+            "FE_L_per_100km": float(np.max(FC_tot / 0.835) / np.max(s / 1000.0) * 100.0)}
+
+
+def fuel_economy_of_speed_trace(V_2Hz, V: Dict[str, float], Ts: float = 0.5) -> float:
+    """The same figure for a vehicle that drives the lead trace itself (ABO/Custom_plots.m:113-155, `FE_lead`;
+    the gear-dependent quantities of that block do not enter the fuel map)."""
+    v = np.asarray(V_2Hz, dtype=np.float64).ravel().copy()
+    v = np.concatenate([v, [0.0]]) if v.size == 870 else v              # V_TO(871,1) = 0 (:117)
+    a = np.concatenate([[0.0], np.diff(v) / Ts])
+    s = np.concatenate([[0.0], np.cumsum(v[1:] * Ts)])
+    return fuel_economy({"a_opt": a, "v_opt": v, "s_opt": s}, V, Ts)["FE_L_per_100km"]

@@ -32,3 +32,27 @@ def test_kpis_of_the_saved_solutions():
 def test_interp_pwa():
     assert InterpPWA(-5, [0, 10], [1, 3]) == 1 and InterpPWA(50, [0, 10], [1, 3]) == 3
     assert abs(InterpPWA(2.5, [0, 10], [1, 3]) - 1.5) < 1e-15
+
+
+def test_fuel_economy_of_saved_solutions():
+    """ABO/Custom_plots.m:73-155: L/100 km of the runs with and without the fuel term and of the lead trace itself.  The
+    reference prints these numbers without storing them, so the check is the formula on hand-computable inputs plus
+    the ordering the script was written to show (the fuel-optimised run uses less than the run without the term)."""
+    import numpy as np
+    from conftest import load_golden
+    from eepacc_mpc_casadi_matlab_amd.report import fuel_economy, fuel_economy_of_speed_trace
+    from eepacc_mpc_casadi_matlab_amd.settings import SetVehicleParameters
+    V = SetVehicleParameters("ABO")
+    # constant 10 m/s for 100 s: TW = (F0 + F2 v^2) R_w, FC = p00 + p10 v + p01 TW (above the 0.25 g/s floor)
+    n = 201
+    sol = dict(a_opt=np.zeros(n), v_opt=np.full(n, 10.0), s_opt=10.0 * 0.5 * np.arange(n))
+    fe = fuel_economy(sol, V)
+    TW = (V["F0"] + V["F2"] * 100.0) * V["R_w"]
+    FC = max(0.25, V["p00"] + V["p10"] * 10.0 + V["p01"] * TW)
+    assert fe["FC"][1] == FC and fe["TW_opt"][1] == TW and fe["FC"][0] == 0.0
+    assert abs(fe["FE_L_per_100km"] - FC / 1000 * 0.5 * (n - 1) / 0.835 / (sol["s_opt"][-1] / 1000) * 100) < 1e-12
+    fc = fuel_economy(load_golden("abo_abmpc_fcopt"), V)["FE_L_per_100km"]
+    nofc = fuel_economy(load_golden("abo_abmpc_nofcopt"), V)["FE_L_per_100km"]
+    lead = fuel_economy_of_speed_trace(load_golden("lead_TO01_EAD")["V_TO_2Hz"], V)
+    # 9.75 (fuel term), 10.20 (no fuel term), 10.58 L/100 km (lead trace): the saving the reference's script shows
+    assert 9.7 < fc < 9.8 and 10.1 < nofc < 10.3 and 10.5 < lead < 10.7
