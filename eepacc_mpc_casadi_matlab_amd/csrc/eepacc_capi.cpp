@@ -216,7 +216,7 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
             Hinv[(size_t)i * N + j] = (double)(0.5L * (H[(size_t)i * N + j] + H[(size_t)j * N + i]));
-    if (eepacc::ab_smem_bytes(N) > 160 * 1024)
+    if (eepacc::ab_smem_bytes(N) > 157 * 1024)
         return fail(EEPACC_ENOTSUP, "N_hor too large for the LDS layout of this build");
     return EEPACC_OK;
 }

@@ -33,7 +33,14 @@ namespace eepacc {
 
 // working-set capacity: rigid rows are linearly independent, so m <= N (+ terminal rows)
 constexpr int kMMaxSmall = 34, kNSSmall = 32;     // N <= 32: 8 waves / CU (4 per block, 2 blocks)
-constexpr int kMMaxLarge = 66, kNSLarge = 64;     // N <= 63: 2 waves / CU
+// N <= 63: 60 KB of LDS per wave (He 32 KB, P 17.7 KB), 2 waves per CU.  Trading working-set capacity for occupancy
+// does not work: with a capacity of 50 rigid rows (3 waves per CU; -DEEPACC_MMAX_LARGE=50 -DEEPACC_WPB_LARGE=3) the S2
+// workload at N = 60 overflows the working set on 15 % of the steps (measured), so the full N + 2 stays.
+#ifndef EEPACC_MMAX_LARGE
+#define EEPACC_MMAX_LARGE 66
+#define EEPACC_WPB_LARGE 2
+#endif
+constexpr int kMMaxLarge = EEPACC_MMAX_LARGE, kNSLarge = 64, kWpbLarge = EEPACC_WPB_LARGE;
 constexpr int kChunkStepsDefault = nomb::kChunkStepsDefault;
 
 #ifdef EEPACC_AB_TIMING
@@ -47,7 +54,7 @@ extern "C" int eepacc_debug_ab_prof(unsigned long long* out, int reset) {
 
 size_t ab_smem_bytes(int N) {
     return N <= kNSSmall ? nomb::wave_bytes(sizeof(nomb::WaveMem<kMMaxSmall, kNSSmall>), kNSSmall) * 4
-                         : nomb::wave_bytes(sizeof(nomb::WaveMem<kMMaxLarge, kNSLarge>), kNSLarge) * 2;
+                         : nomb::wave_bytes(sizeof(nomb::WaveMem<kMMaxLarge, kNSLarge>), kNSLarge) * kWpbLarge;
 }
 
 // the kernel of the namespace with / without move blocking, small or large horizon
@@ -75,7 +82,7 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double*
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream) {
-    if (N > kNSSmall) EEPACC_LAUNCH(k_ab_step, kMMaxLarge, kNSLarge, 2, (B + 1) / 2, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
+    if (N > kNSSmall) EEPACC_LAUNCH(k_ab_step, kMMaxLarge, kNSLarge, kWpbLarge, (B + kWpbLarge - 1) / kWpbLarge, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
     else EEPACC_LAUNCH(k_ab_step, kMMaxSmall, kNSSmall, 4, (B + 3) / 4, dC, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, codes, out, s_pred, v_pred, status, iters);
     return hipGetLastError();
 }
@@ -93,16 +100,16 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start
         e = hipMemsetAsync(iters_total, 0, sizeof(int32_t) * (size_t)B, stream);
         if (e != hipSuccess) return e;
     }
-    const int kChunkSteps = pick_chunk_steps(n_steps, B, num_cus * (N > kNSSmall ? 2 : 8));
+    const int kChunkSteps = pick_chunk_steps(n_steps, B, num_cus * (N > kNSSmall ? kWpbLarge : 8));
     // bound of the inter-unit spin wait (a debug hook lowers it to exercise the failure path)
     int spin_limit = 1 << 26;
     if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) spin_limit = atoi(ev);
     const int n_units = ((n_steps + kChunkSteps - 1) / kChunkSteps) * B;
     // one chip-filling wave of blocks: LDS admits 8 (small) / 2 (large) waves per CU
     if (N > kNSSmall) {
-        int grid = num_cus * 1, need = (n_units + 1) / 2;
+        int grid = num_cus * 1, need = (n_units + kWpbLarge - 1) / kWpbLarge;
         if (grid > need) grid = need;
-        EEPACC_LAUNCH(k_run_abmpc, kMMaxLarge, kNSLarge, 2, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
+        EEPACC_LAUNCH(k_run_abmpc, kMMaxLarge, kNSLarge, kWpbLarge, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
     } else {
         int grid = num_cus * 2, need = (n_units + 3) / 4;
         if (grid > need) grid = need;
@@ -119,15 +126,18 @@ hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double
 
 hipError_t set_max_smem() {
     const void* fns[8] = {reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxLarge, kNSLarge, 2>),
+                          reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxLarge, kNSLarge, 2>),
+                          reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&withmb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&withmb::k_ab_step<kMMaxLarge, kNSLarge, 2>),
+                          reinterpret_cast<const void*>(&withmb::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxLarge, kNSLarge, 2>)};
+                          reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>)};
     for (int i = 0; i < 8; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // the rest holds the static index table
+        // 160 KB of LDS per CU minus the kernel's static index table (one ushort per packed entry of P)
+        const int mm = (i & 1) ? kMMaxLarge : kMMaxSmall;
+        const int dyn = 160 * 1024 - ((mm * (mm + 1) / 2 * 2 + 255) & ~255);
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

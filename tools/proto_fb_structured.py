@@ -252,7 +252,14 @@ class StructuredFB:
         if st["P"]:
             r = p.rows[st["pivot"]]
             if r["aw"] != 0 and self.wst[r["k"]]["P"]:
-                self.unsupported = True           # (xi_f, w) both off their bounds through coupled rows
+                # the pivot of xi_f contains w and w is off its bound: representable if w's own pivot is free of xi_f
+                # (w first, then xi_f); both pivots among the coupled rows would need a 2 x 2 solve
+                q = p.rows[self.wst[r["k"]]["pivot"]]
+                if q["grp"] is not None:
+                    self.unsupported = True
+                    return r["n"], -r["b"]
+                nw, cw = self.w_expr(r["k"])
+                return r["n"] + r["aw"] * nw, -r["b"] + r["aw"] * cw
             return r["n"], -r["b"]
         return z, G["lb"]
 
@@ -531,7 +538,7 @@ class StructuredFB:
                 var = key[1]; is_w = var == "w"
                 st = self.wst[k] if is_w else self.gstate[var]
                 cands = self.members(k, var, ("none",), 0.0)
-                if not is_w and self.wst[k]["P"]:
+                if not is_w and self.wst[k]["P"] and p.rows[self.wst[k]["pivot"]]["grp"] is not None:
                     cands = [c for c in cands if p.rows[c[0]]["aw"] == 0] or cands
                 if cands:
                     j = max(cands, key=lambda c: c[1])[0]
@@ -710,13 +717,16 @@ class StructuredFB:
             is_w = var == "w"
             st = self.wst[k] if is_w else self.gstate[var]
             cands = self.members(k, var, q, lam_q)
-            if not is_w and self.wst[k]["P"]:
-                # a pivot of xi_f that contains w while w is off its bound would couple the two eliminations
+            if not is_w and self.wst[k]["P"] and p.rows[self.wst[k]["pivot"]]["grp"] is not None:
+                # a pivot of xi_f that contains w while w's pivot contains xi_f would couple the two eliminations
                 cands = [c for c in cands if p.rows[c[0]]["aw"] == 0] or cands
             if is_w:
                 stF = self.gstate[("f", k)]
                 if stF["P"] and p.rows[stF["pivot"]]["aw"] != 0:
-                    self.unsupported = True
+                    # xi_f is defined through a row that contains w: w may only be pinned by a row free of xi_f
+                    cands = [c for c in cands if p.rows[c[0]]["grp"] is None]
+                    if not cands:
+                        self.unsupported = True
             q_bound_here = (q[0] == "wbound" and is_w and q[1] == k) or (q[0] == "bound" and q[1] == var)
             if key[0] == "mu":                 # bound multiplier reached zero: the variable leaves its bound
                 if not cands:
