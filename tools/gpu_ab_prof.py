@@ -34,4 +34,5 @@ for i, nm in enumerate(names):
 P("passes/step", prof[13] / (B * 200.0))
 for i, nm in enumerate(why_names):
     P(f"  full rebuilds/step because {nm:20s} {prof[14 + i] / (B * 200.0):.3f}")
+P("carried passes/step", (prof[23] % 1000) / (B * 200.0), "(low digits only)  raw", prof[23] / (B * 200.0))
 P("iterations/step", eng.last_iterations(B).mean() / 200)
