@@ -182,9 +182,13 @@ __device__ __forceinline__ int pivot_of(const Lane& L, int g) {
 }
 __device__ __forceinline__ int wpivot_of(const Lane& L) {
     if (L.lane >= L.N) return -1;
-    const unsigned long long three = codes_eq3(L.code) & ((1ull << (2 * F_FMLO)) | (1ull << (2 * F_TQMIN)) | (1ull << (2 * F_RTLO)));
+    const unsigned long long three = codes_eq3(L.code) & ((1ull << (2 * F_FMLO)) | (1ull << (2 * F_FBLO)) | (1ull << (2 * F_TQMIN)) | (1ull << (2 * F_RTLO)));
     return three ? ((__ffsll((long long)three) - 1) >> 1) : -1;
 }
+// the pivot of w is one of the rows that also carry xi_f (torque / rear-axle limit): then xi_f must be defined first,
+// by a row free of w.  Otherwise (motor-force bound, or w on its upper bound = pivot F_FBLO) w is defined first and
+// the pivot of xi_f may contain it.
+__device__ __forceinline__ bool wpivot_in_F(int p) { return p == F_TQMIN || p == F_RTLO; }
 
 // homogeneous response to the per-lane input x (lane k < N holds x_k): vh_k = Pi_k sum_{i<k} gamma_i x_i,
 // sh_k = sum_{i<k} T_i vh_i
@@ -280,7 +284,7 @@ __device__ __forceinline__ Tup w_expr(const Lane& L, const RC& c, const double* 
     const int q = wpivot_of(L);
     if (q < 0) return W;
     const double ia = -1.0 / row_aw(q, c);
-    const bool inF = q != F_FMLO;
+    const bool inF = wpivot_in_F(q);
     W.al = (row_al(q) - (inF ? XF.al : 0.0)) * ia;
     W.be = (row_be(q, c, L.chw) - (inF ? XF.be : 0.0)) * ia;
     W.ga = (row_ga(q, c) - (inF ? XF.ga : 0.0)) * ia;
@@ -295,6 +299,13 @@ __device__ __forceinline__ Locals locals_of(const Lane& L, const RC& c, const do
     S.XF = xi_expr<NS>(L, c, ba, GF); S.XS = xi_expr<NS>(L, c, ba, GS); S.XV = xi_expr<NS>(L, c, ba, GV);
     S.XH = xi_expr<NS>(L, c, ba, GH);
     S.W = w_expr<NS>(L, c, ba, S.XF);
+    const int pW = wpivot_of(L);
+    if (pW >= 0 && !wpivot_in_F(pW)) {
+        // w first: a pivot of xi_f that contains w sees it through w's own expression
+        const int pF = pivot_of(L, GF);
+        const double aw = pF >= 0 ? row_aw(pF, c) : 0.0;
+        if (aw != 0.0) { S.XF.al += aw * S.W.al; S.XF.be += aw * S.W.be; S.XF.ga += aw * S.W.ga; S.XF.de += aw * S.W.de; S.XF.c += aw * S.W.c; }
+    }
     return S;
 }
 __device__ __forceinline__ const Tup& xi_of(const Locals& S, int g) { return g == GF ? S.XF : (g == GS ? S.XS : (g == GV ? S.XV : S.XH)); }
@@ -397,10 +408,10 @@ __device__ __forceinline__ void he_sync(Lane& L, const RC& c, FMem<MMAX, NS>& M,
     }
     L.kmask = want;
     // bilinear terms of the stages whose w is off its bound
-    if (L.wmask == 0ull && !__any(wpivot_of(L) >= 0)) return;
+    if (L.wmask == 0ull && !__any(wpivot_of(L) >= 0 && wpivot_of(L) != F_FBLO)) return;
     const Tup XF = xi_expr<NS>(L, c, M.ba, GF);
     const Tup W = w_expr<NS>(L, c, M.ba, XF);
-    const bool wantP = wpivot_of(L) >= 0;
+    const bool wantP = wpivot_of(L) >= 0 && wpivot_of(L) != F_FBLO;     // on its upper bound w is a constant: nothing to fold
     const bool folded = ((L.wmask >> L.lane) & 1ull) != 0ull;
     const bool same = wantP && folded && W.al == L.fal && W.be == L.fbe && W.ga == L.fga && W.de == L.fde;
     unsigned long long rem = __ballot(folded && !same), addm = __ballot(wantP && !same);
@@ -706,7 +717,7 @@ __device__ __forceinline__ LocalMults local_mults(const Lane& L, const RC& c, co
     if (pW >= 0) {
         const double ia = -1.0 / row_aw(pW, c);
         swv *= ia; swr *= ia;    // multiplier of the pivot row of w
-        if (pW != F_FMLO) { vF -= swv; rF -= swr; }
+        if (wpivot_in_F(pW)) { vF -= swv; rF -= swr; }
     }
     o.vF = vF; o.rF = rF; o.vW = swv; o.rW = swr;
     return o;
@@ -801,7 +812,7 @@ __device__ __forceinline__ int warm_repair(Lane& L, const RC& c, const FMem<MMAX
         } else {
             const int p = pivot_of(L, et);
             if (p >= 0) set_code(L, p, 0);
-            int bestt = et == GF ? ((wpivot_of(L) >= 0 && bF0 >= 0) ? bF0 : bF) : (et == GS ? bS : bV);
+            int bestt = et == GF ? ((wpivot_in_F(wpivot_of(L)) && bF0 >= 0) ? bF0 : bF) : (et == GS ? bS : bV);
             if (bestt >= 0 && code_of(L, bestt) == 1) set_code(L, bestt, 2);
         }
     }
@@ -1094,9 +1105,14 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         bool finished = false;
         if (t2 <= t1) {
             // full step: the incoming constraint becomes active
-            if (!q.is_bound && m > 0) { F.fast = 1; F.kq = kq; F.tq = q.tq; F.zz = zz; }
+            // w reaches its upper bound (Fb = -1e4 N) while a row defines it: the bound row takes over as w's pivot (the
+            // canonical form of "w on its upper bound": free of xi_f, so rows that contain w may define xi_f) and the
+            // former pivot becomes an ordinary working-set row
+            const bool w_upper = !q.is_bound && q.tq == F_FBLO && bcast_i(wpivot_of(L), kq) >= 0;
+            if (!q.is_bound && m > 0 && !w_upper) { F.fast = 1; F.kq = kq; F.tq = q.tq; F.zz = zz; }
             if (lane == kq) {
-                if (!q.is_bound) set_code(L, q.tq, 1);
+                if (w_upper) { set_code(L, wpivot_of(L), 1); set_code(L, F_FBLO, 3); }
+                else if (!q.is_bound) set_code(L, q.tq, 1);
                 else if (q.gq == GH) set_code(L, F_HWP, 1);
                 else if (q.gq == GW) { const int p = wpivot_of(L); set_code(L, p, 1); }
                 else { const int p = pivot_of(L, q.gq); set_code(L, p, 1); }
@@ -1124,6 +1140,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                     const int g2 = et;
                     // candidates: active members of the group with their (weighted) multipliers after the step
                     int bestm = -1, bestm0 = -1; double bl = -1e300, bl0 = -1e300;
+                    bool fmlo_cand = false;
                     int pos = L.base;
 #pragma unroll
                     for (int t = 0; t < kNumF; ++t) {
@@ -1131,7 +1148,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                         const double l = M.lam[pos] - tstep * M.rv[pos];
                         ++pos;
                         const double aw = row_aw(t, c);
-                        if (g2 == GW) { if (is_relax(t) && -aw * l > bl) { bl = -aw * l; bestm = t; } }
+                        if (g2 == GW) { if (is_relax(t) && -aw * l > bl) { bl = -aw * l; bestm = t; } if (t == F_FMLO) fmlo_cand = true; }
                         else if (t >= F_TQMIN && t <= F_VINC && group_of(t) == g2) {
                             if (l > bl) { bl = l; bestm = t; }
                             if (aw == 0.0 && l > bl0) { bl0 = l; bestm0 = t; }
@@ -1141,8 +1158,13 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                     if (g2 == GW) {
                         const int p = wpivot_of(L);
                         const int pF = pivot_of(L, GF);
-                        if (pF >= 0 && row_aw(pF, c) != 0.0) L.unsup = 1;      // (xi_f, w) coupled through their pivots
-                        const bool q_row_here = q_here && is_relax(q.tq);
+                        bool q_row_here = q_here && is_relax(q.tq);
+                        if (pF >= 0 && row_aw(pF, c) != 0.0) {
+                            // xi_f is defined through a row that contains w: w may only be pinned by a row free of xi_f
+                            bestm = fmlo_cand ? (int)F_FMLO : -1;
+                            q_row_here = q_row_here && q.tq == F_FMLO;
+                            if (bestm < 0 && !q_row_here && bl > -1e299) L.unsup = 1;      // (xi_f, w) coupled through their pivots
+                        }
                         const bool q_bound_here = (kq == el) && q.is_bound && q.gq == GW;
                         if (p >= 0) set_code(L, p, 0);
                         if (bestm >= 0) set_code(L, bestm, 3);
@@ -1154,7 +1176,7 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                         const bool q_row_here = q_here && q.gq == g2;
                         const bool q_bound_here = (kq == el) && q.is_bound && q.gq == g2;
                         // a pivot of xi_f that contains w while w is off its bound would couple the two eliminations
-                        if (g2 == GF && wpivot_of(L) >= 0) { bestm = bestm0; if (bestm0 < 0 && bl > -1e299) L.unsup = 1; }
+                        if (g2 == GF && wpivot_in_F(wpivot_of(L))) { bestm = bestm0; if (bestm0 < 0 && bl > -1e299) L.unsup = 1; }
                         if (p < 0) {                       // on the bound -> off it
                             if (bestm < 0) { if (q_row_here) { set_code(L, q.tq, 2); fin = 1; } else L.unsup = 1; }
                             else set_code(L, bestm, 2);
@@ -1483,8 +1505,16 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     const double u0 = bcast(L.u, 0), w0 = bcast(w, 0);
     so.out[EEPACC_OUT_S] = in.s;
     so.out[EEPACC_OUT_V] = in.v;
-    so.out[EEPACC_OUT_FM] = u0 + w0;                                            // :294-299
-    so.out[EEPACC_OUT_FB] = -w0;
+    double Fm0 = u0 + w0, Fb0 = -w0;                                            // :294-299
+    if (so.status != 0 || st.status != 0) {
+        // no solution (or the iteration gave up): the last iterate is applied like the reference does
+        // (opts.error_on_fail = false), projected on the actuators' hard bounds (CreateQP_FB.m:319-326) so that the
+        // plant state stays finite whatever the iterate was
+        Fm0 = (Fm0 == Fm0) ? fmin(fmax(Fm0, -1e4), 1e4) : 0.0;
+        Fb0 = (Fb0 == Fb0) ? fmin(fmax(Fb0, -1e4), 0.0) : 0.0;
+    }
+    so.out[EEPACC_OUT_FM] = Fm0;
+    so.out[EEPACC_OUT_FB] = Fb0;
     so.out[EEPACC_OUT_A] = in.have_vprev ? (in.v - in.v_prev) / C.Tvec[0] : 0.0;  // :316-318
     so.out[EEPACC_OUT_XI_V] = bcast(xiV, 0);
     so.out[EEPACC_OUT_XI_H] = bcast(xiH, 0);

@@ -49,7 +49,9 @@ def _compare_fb(tr, st, ref, rst, scale=1.0, dense_path=False):
     if n == 0:
         return 0
     for nm in ("s", "v", "a", "xi_v", "xi_h", "xi_s", "xi_f", "DistHor"):
-        assert np.abs(t[:, OUT[nm]] - r[:, OUT[nm]]).max() < scale * TOL[nm], nm
+        # xi_f is a force here (N; > 1e4 in an emergency first step): relative part like the forces below
+        rel = 1e-11 * np.abs(r[:, OUT[nm]]).max() if nm == "xi_f" else 0.0
+        assert np.abs(t[:, OUT[nm]] - r[:, OUT[nm]]).max() < scale * TOL[nm] + rel, nm
     Fr = r[:, OUT["Fm"]] + r[:, OUT["Fb"]]
     ftol = scale * 1e-6 + 1e-8 * np.abs(Fr).max()             # forces reach 1e4 N in hard braking
     assert np.abs(t[:, OUT["Fm"]] + t[:, OUT["Fb"]] - Fr).max() < ftol
@@ -203,12 +205,11 @@ def test_fb_closed_loop_s2_n30_vs_oracle(torch_mod, lead_trace):
     assert braked >= 3, braked
 
 
-def test_fb_known_limit_emergency_first_step(torch_mod, lead_trace):
-    """Known limit of the structured kernel, stated as a test: an emergency first step that needs the whole
-    friction brake (Fb = -1e4 N, CreateQP_FB.m:70, with a large xi_f) puts the friction-brake share w on its UPPER
-    bound, a state the kernel's elimination of (w, xi_f) does not represent; it reports
-    status 1 there while the dense oracle still finds the KKT point.  In the first 64 S2 scenarios this happens on
-    three instances, only at step 0 (0.1 % of their first 40 steps); everything else has equal exit flags."""
+def test_fb_emergency_first_step(torch_mod, lead_trace):
+    """Emergency first steps that need the whole friction brake (Fb = -1e4 N, CreateQP_FB.m:70, with a large xi_f):
+    the friction-brake share w sits on its UPPER bound, represented by making the bound row w's pivot (DESIGN.md
+    section 3.5).  First 64 S2 scenarios, step 0: exit flags equal the oracle's everywhere (instances 33, 44, 51 are
+    the ones on the bound), total force within 1e-4 N of the oracle's."""
     from oracle import Oracle
     OPT, V, _, _ = make_case("ABO", 30)
     B, n_steps = 64, 6
@@ -225,10 +226,9 @@ def test_fb_known_limit_emergency_first_step(torch_mod, lead_trace):
             assert st[0, i] != 0                       # never a success where the oracle fails
         elif st[0, i] != 0:
             gave_up.append(i)
-            assert ref[0, OUT["Fb"]] < -9999.0                # the friction brake is on its bound Fb = -1e4 N
         else:
             assert abs(tr[0, OUT["Fm"], i] + tr[0, OUT["Fb"], i] - ref[0, OUT["Fm"]] - ref[0, OUT["Fb"]]) < 1e-4
-    assert len(gave_up) <= 4, gave_up                  # measured: instances 33, 44, 51
+    assert not gave_up, gave_up
 
 
 def test_fb_step_operator_vs_oracle(torch_mod):

@@ -99,3 +99,30 @@ def test_structured_fb_hard_braking():
 
     _loop(OPT, V, orc, float(sc["v0"][16]), sc["s_tv"][:, 16], sc["v_tv"][:, 16], 6, check)
     assert max(used_w) > 100.0           # the friction brake really was in use
+
+
+def test_structured_fb_emergency_first_step():
+    """S2 instance 33 (N = 30), step 0: the whole friction brake is needed (Fb = -1e4 N) together with a large xi_f.
+    w sits on its upper bound: the bound row becomes w's pivot and rows that contain w may then define xi_f.  Dense
+    feasibility and objective against the oracle's dense QP."""
+    OPT, V, _, _ = make_case("ABO", 30)
+    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
+    sc = make_s2(34, 2, lead["V_TO_2Hz"])
+    orc = Oracle(OPT, V)
+    seen = []
+
+    def check(kk, r, prob, qp, status):
+        assert status == 0 and r["status"] == 0, (kk, status, r["status"])
+        x, u, w = _dense_x(prob, qp)
+        xr = r["x"]
+        Gx = r["G"] @ x
+        assert max(np.max(Gx - r["ub"]), np.max(r["lb"] - Gx)) < 1e-6
+        H, c = r["H"], r["c"]
+        cp, co = 0.5 * x @ H @ x + c @ x, 0.5 * xr @ H @ xr + c @ xr
+        assert abs(cp - co) < 1e-9 * abs(co)
+        assert abs(x[0] + x[1] - xr[0] - xr[1]) < 1e-4 and abs(x[1] + 1e4) < 1e-6 and abs(xr[1] + 1e4) < 1e-6
+        assert qp.wst[0]["P"] and prob.rows[qp.wst[0]["pivot"]]["name"] == "fb_lo"
+        seen.append(kk)
+
+    _loop(OPT, V, orc, float(sc["v0"][33]), sc["s_tv"][:, 33], sc["v_tv"][:, 33], 1, check)
+    assert seen == [0]

@@ -653,6 +653,15 @@ class StructuredFB:
         p = self.p
         if q[0] == "row":
             j = q[1]
+            r = p.rows[j]
+            if r["name"] == "fb_lo" and self.wst[r["k"]]["P"]:
+                # w reaches its upper bound: the bound row becomes w's pivot (canonical form of "w on its upper bound",
+                # free of xi_f, so that rows containing w may define xi_f), the former pivot turns into an ordinary row
+                st = self.wst[r["k"]]
+                old = st["pivot"]
+                st["pivot"] = j
+                self.W.append(old); self.lam[old] = 0.0
+                return
             self.W.append(j); self.lam[j] = lam_q
             return
         if q[0] == "wbound":
