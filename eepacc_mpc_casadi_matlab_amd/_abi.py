@@ -49,6 +49,12 @@ class SettingsPOD(C.Structure):
         ("n_TL", C.c_int32), ("TLLoc", c_double_p),
         ("stopRefDist", C.c_double), ("stopRefVelSlope", C.c_double), ("stopVel", C.c_double),
         ("TLstopVel", C.c_double), ("TLStopRegionSize", C.c_double), ("alpha_TTL", C.c_double),
+        ("bl_mode", C.c_int32), ("bl_pad", C.c_int32),
+        ("W_BL", C.c_double * 4),
+        ("BL_a_LimLowVel", C.c_double), ("BL_a_LimHighVel", C.c_double),
+        ("BL_j_LimLowVel", C.c_double), ("BL_j_LimHighVel", C.c_double),
+        ("bl_lp_eps", C.c_double),
+        ("state_bound_tol", C.c_double),
     ]
 
 
@@ -112,6 +118,15 @@ class SettingsHolder:
         p.stopRefDist = float(OPT["stopRefDist"]); p.stopRefVelSlope = float(OPT["stopRefVelSlope"])
         p.stopVel = float(OPT["stopVel"]); p.TLstopVel = float(OPT["TLstopVel"])
         p.TLStopRegionSize = float(OPT["TLStopRegionSize"]); p.alpha_TTL = float(OPT["alpha_TTL"])
+        # baseline controller (RunOpt_BLMPC): settings.Settings_BL() fills these
+        p.state_bound_tol = float(OPT.get("state_bound_tol", 0.0))
+        p.bl_mode = int(OPT.get("bl_mode", 0))
+        if p.bl_mode:
+            for i in range(4):
+                p.W_BL[i] = float(np.asarray(OPT["W_BL"]).ravel()[i])
+            p.BL_a_LimLowVel = float(OPT["BL_a_LimLowVel"]); p.BL_a_LimHighVel = float(OPT["BL_a_LimHighVel"])
+            p.BL_j_LimLowVel = float(OPT["BL_j_LimLowVel"]); p.BL_j_LimHighVel = float(OPT["BL_j_LimHighVel"])
+            p.bl_lp_eps = float(OPT.get("bl_lp_eps", 0.0))
 
     def _dptr(self, arr, n=None):
         a = np.ascontiguousarray(arr, dtype=np.float64).ravel()

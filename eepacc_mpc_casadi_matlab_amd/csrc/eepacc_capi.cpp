@@ -15,11 +15,11 @@
 
 namespace eepacc {
 size_t ab_smem_bytes(int N);
-hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double* s, const double* v, const double* a_prev,
+hipError_t launch_ab_step(const DevCfg* dC, int N, int variant, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream);
-hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start, int n_steps, const double* s0,
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, int variant, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
                             int32_t* status, int32_t* iters_total, int* work_counter, int* done, int* err_word, int num_cus,
@@ -94,6 +94,9 @@ static bool spd_inverse(std::vector<long double>& A, int n) {
     return true;
 }
 
+// kernel variant of a handle: 0 plain, 1 blocked moves, 2 baseline controller
+static int ab_variant(const DevCfg& C) { return C.bl_mode ? 2 : (C.mb_any ? 1 : 0); }
+
 static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& C, std::vector<double>& Hinv) {
     memset(&C, 0, sizeof(C));
     const int N = S->N_hor;
@@ -151,7 +154,26 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     C.mb_mask[N] = 0;
     C.w_FC = S->ab_fuel_term ? S->W_AB[0] : 0.0;
     C.w_a = S->W_AB[1]; C.w_j = S->W_AB[2]; C.w_v = S->W_AB[3]; C.w_h = S->W_AB[4]; C.w_s = S->W_AB[5]; C.w_f = S->W_AB[6];
-    if (!(C.w_a > 0.0) || !(C.w_h > 0.0) || C.w_v < 0 || C.w_s < 0 || C.w_f < 0 || C.w_j < 0)
+    // default: the noise level of the closed loop at standstill -- ABMPC 1e-10, the baseline LP (solved with curvature
+    // 1e-4, accelerations good to a few 1e-9) 2e-9
+    C.state_tol = S->state_bound_tol > 0.0 ? S->state_bound_tol : (S->bl_mode ? 1e-7 : 1e-9);
+    double bl_travel = 0.0;
+    if (S->bl_mode) {
+        // RunOpt_BLMPC: CreateQP_BL.m:36-39,131-148  W_BL = [w_v (travel incentive), w_a, w_j, w_f]
+        if (S->bl_mode != 1) return fail(EEPACC_EINVAL, "bl_mode must be 0 or 1");
+        if (C.mb_any) return fail(EEPACC_ENOTSUP, "the baseline controller has no move blocking (RunOpt_BLMPC.m)");
+        if (S->W_BL[0] < 0 || S->W_BL[1] < 0 || S->W_BL[2] < 0 || !(S->W_BL[3] > 0))
+            return fail(EEPACC_EINVAL, "W_BL weights must be non-negative (w_f positive)");
+        C.bl_mode = 1;
+        C.ab_fuel_term = 0; C.ab_route_rows = 1;            // CreateQP_BL.m:264-288: the four speed caps are always present
+        C.w_FC = 0.0; C.w_a = S->W_BL[1]; C.w_j = S->W_BL[2]; C.w_f = S->W_BL[3];
+        C.w_v = 0.0; C.w_s = 0.0; C.w_h = 1.0;              // groups that do not exist in the baseline QP
+        bl_travel = S->W_BL[0];
+        C.bl_eps = (C.w_a == 0.0 && C.w_j == 0.0) ? (S->bl_lp_eps > 0.0 ? S->bl_lp_eps : 1e-4) : 0.0;
+        C.bl_aLo = S->BL_a_LimLowVel; C.bl_aHi = S->BL_a_LimHighVel; C.bl_jLo = S->BL_j_LimLowVel; C.bl_jHi = S->BL_j_LimHighVel;
+        if (!(C.bl_aLo > 0) || !(C.bl_aHi > 0) || !(C.bl_jLo > 0) || !(C.bl_jHi > 0))
+            return fail(EEPACC_EINVAL, "baseline acceleration / jerk limits must be positive");
+    } else if (!(C.w_a > 0.0) || !(C.w_h > 0.0) || C.w_v < 0 || C.w_s < 0 || C.w_f < 0 || C.w_j < 0)
         return fail(EEPACC_EINVAL, "W_AB weights must be positive (w_a, w_h) / non-negative");
     C.tau_min = S->tau_min; C.h_min = S->h_min; C.s_goal = S->s_goal;
     C.tConstACC_ego = S->tConstACC_ego; C.tConstACC_tar = S->tConstACC_tar;
@@ -160,7 +182,7 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     C.eta_TF = V->eta_TF; C.omega_m_r = V->omega_m_r; C.v_max = V->v_max;
     C.p01 = V->p01; C.p10 = V->p10; C.F2 = V->F2;
     C.cq = C.w_FC * V->p01 * V->F2;
-    C.glin_v = C.w_FC * V->p10;
+    C.glin_v = C.bl_mode ? -bl_travel : C.w_FC * V->p10;
     C.glin_a = C.w_FC * V->p01 * V->lambda * V->m;
     C.n_speedLim = S->n_speedLim; C.n_curv = S->n_curv; C.n_slope = S->n_slope; C.n_stop = S->n_stop; C.n_TL = S->n_TL;
     for (int i = 0; i < S->n_speedLim; ++i) { C.s_speedLim[i] = S->s_speedLim[i]; C.v_speedLim[i] = S->v_speedLim[i]; }
@@ -193,7 +215,7 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
             if (cnt > 0) H[(size_t)i * N + j] += 2.0L * C.cq * C.Tvec[i] * C.Tvec[j] * cnt;
         }
     for (int k = 0; k < N; ++k) {
-        H[(size_t)k * N + k] += 2.0L * C.w_a;
+        H[(size_t)k * N + k] += 2.0L * C.w_a + (long double)C.bl_eps;
         long double qj = 2.0L * C.w_j / ((long double)C.Tvec[k] * C.Tvec[k]);
         H[(size_t)k * N + k] += qj;
         if (k > 0) {
@@ -340,7 +362,7 @@ extern "C" int eepacc_ab_step(eepacc_handle* h, int B, const double* s, const do
         return fail(EEPACC_EINVAL, "eepacc_ab_step: NULL buffer");
     HIPCHK(hipSetDevice(h->device));
     h->last_B = B;
-    HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, h->cfg.mb_any != 0, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
+    HIPCHK(eepacc::launch_ab_step(h->d_cfg, h->cfg.N, ab_variant(h->cfg), B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, h->d_codes, out,
                                   s_pred, v_pred, status, h->d_iters, (hipStream_t)stream));
     return EEPACC_OK;
 }
@@ -357,7 +379,7 @@ extern "C" int eepacc_run_abmpc(eepacc_handle* h, int B, int n_steps, const doub
     if (h->k_done > 0 && h->carry_B != B)
         return fail(EEPACC_EINVAL, "eepacc_run_abmpc: B changed while resuming; call eepacc_reset first");
     h->last_B = B;
-    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, h->cfg.mb_any != 0, B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
+    HIPCHK(eepacc::launch_run_abmpc(h->d_cfg, h->cfg.N, ab_variant(h->cfg), B, h->k_done, n_steps, s0, v0, a_minus1, s_tv, v_tv,
                                     h->d_carry, h->d_codes, traj, status, h->d_iters, h->d_counter, h->d_done, h->d_err, h->num_cus,
                                     (hipStream_t)stream));
     h->k_done += n_steps; h->carry_B = B;

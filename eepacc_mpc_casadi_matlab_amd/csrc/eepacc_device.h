@@ -65,6 +65,11 @@ struct DevCfg {
     // FBMPC row layout: stage k owns rows fb_row0[k] .. fb_row0[k+1]-1 (26, or 28 with its two blocked-move rows)
     int32_t fb_row0[kMaxN + 2];
     int32_t mb_mask[kMaxN + 1];
+    // baseline controller (RunOpt_BLMPC / CreateQP_BL): one slack group, travel incentive -w_v sum v_k
+    int32_t bl_mode, bl_pad;
+    double bl_eps;                // curvature added to an LP (w_a = w_j = 0); excluded from the reported cost
+    double state_tol;             // tolerance of the hard bounds on the measured state (constant rows of stage 0)
+    double bl_aLo, bl_aHi, bl_jLo, bl_jHi;   // BL_a_LimLowVel, BL_a_LimHighVel, BL_j_LimLowVel, BL_j_LimHighVel
 };
 
 }  // namespace eepacc

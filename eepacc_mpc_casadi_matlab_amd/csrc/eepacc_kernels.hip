@@ -18,6 +18,7 @@
 
 #define EEPACC_IMPL_NS nomb
 #define EEPACC_IMPL_MB false
+#define EEPACC_IMPL_BL false
 #include "eepacc_ab_impl.inc"
 #undef EEPACC_IMPL_NS
 #undef EEPACC_IMPL_MB
@@ -26,6 +27,15 @@
 #include "eepacc_ab_impl.inc"
 #undef EEPACC_IMPL_NS
 #undef EEPACC_IMPL_MB
+#undef EEPACC_IMPL_BL
+// baseline controller (RunOpt_BLMPC): the same kernels with CreateQP_BL's row grouping
+#define EEPACC_IMPL_NS blc
+#define EEPACC_IMPL_MB false
+#define EEPACC_IMPL_BL true
+#include "eepacc_ab_impl.inc"
+#undef EEPACC_IMPL_NS
+#undef EEPACC_IMPL_MB
+#undef EEPACC_IMPL_BL
 
 // ----------------------------------------------------------------------------------------------
 // host-side launchers used by eepacc_capi.cpp
@@ -61,7 +71,8 @@ size_t ab_smem_bytes(int N) {
 #define EEPACC_LAUNCH_NS(NSP, KERNEL, MM, NSV, WPB, GRID, ...)                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(NSP::KERNEL<MM, NSV, WPB>), dim3(GRID), dim3(64 * WPB), ab_smem_bytes(N), stream, __VA_ARGS__)
 #define EEPACC_LAUNCH(KERNEL, MM, NSV, WPB, GRID, ...)                                                        \
-    do { if (mb) EEPACC_LAUNCH_NS(withmb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);                           \
+    do { if (variant == 2) EEPACC_LAUNCH_NS(blc, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);                    \
+         else if (variant == 1) EEPACC_LAUNCH_NS(withmb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);            \
          else EEPACC_LAUNCH_NS(nomb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__); } while (0)
 
 // MPC steps per work unit of the closed-loop kernels: 16 (EEPACC_CHUNK overrides), fewer when the launch is so short
@@ -78,7 +89,7 @@ int pick_chunk_steps(int n_steps, int B, int resident_waves) {
     return c < 2 ? 2 : c;
 }
 
-hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double* s, const double* v, const double* a_prev,
+hipError_t launch_ab_step(const DevCfg* dC, int N, int variant, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
                           int32_t* status, int32_t* iters, hipStream_t stream) {
@@ -87,7 +98,7 @@ hipError_t launch_ab_step(const DevCfg* dC, int N, bool mb, int B, const double*
     return hipGetLastError();
 }
 
-hipError_t launch_run_abmpc(const DevCfg* dC, int N, bool mb, int B, int k_start, int n_steps, const double* s0,
+hipError_t launch_run_abmpc(const DevCfg* dC, int N, int variant, int B, int k_start, int n_steps, const double* s0,
                             const double* v0, const double* a_m1, const double* s_tv, const double* v_tv,
                             double* carry, unsigned long long* codes, double* traj,
                             int32_t* status, int32_t* iters_total, int* work_counter, int* done, int* err_word, int num_cus,
@@ -125,15 +136,19 @@ hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double
 }
 
 hipError_t set_max_smem() {
-    const void* fns[8] = {reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
+    const void* fns[12] = {reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&withmb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&withmb::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>)};
-    for (int i = 0; i < 8; ++i) {
+                          reinterpret_cast<const void*>(&withmb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>),
+                          reinterpret_cast<const void*>(&blc::k_ab_step<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&blc::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
+                          reinterpret_cast<const void*>(&blc::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&blc::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>)};
+    for (int i = 0; i < 12; ++i) {
         // 160 KB of LDS per CU minus the kernel's static index table (one ushort per packed entry of P)
         const int mm = (i & 1) ? kMMaxLarge : kMMaxSmall;
         const int dyn = 160 * 1024 - ((mm * (mm + 1) / 2 * 2 + 255) & ~255);

@@ -72,6 +72,17 @@ __device__ inline void route_bounds(const DevCfg& C, double s_est, double v_est,
             }
         }
     }
+    if (C.bl_mode) {
+        // baseline limits, EstimateRouteAndComfortBounds.m:173-189 (MPCtype 1)
+        double a, j;
+        if (v_est < 5.0) { a = C.bl_aLo; j = C.bl_jLo; }
+        else if (v_est < 20.0) {
+            a = (4.0 * C.bl_aLo - C.bl_aHi) / 3.0 + (C.bl_aHi - C.bl_aLo) / 15.0 * v_est;
+            j = (4.0 * C.bl_jLo - C.bl_jHi) / 3.0 + (C.bl_jHi - C.bl_jLo) / 15.0 * v_est;
+        } else { a = C.bl_aHi; j = C.bl_jHi; }
+        a_min = -a; a_max = a; j_min = -j; j_max = j;
+        return;
+    }
     if (v_est < 5.0) { a_min = -5.0; a_max = 4.0; j_min = -5.0; j_max = 5.0; }
     else if (v_est < 20.0) {
         a_min = -5.5 + v_est / 10.0; a_max = 14.0 / 3.0 - 2.0 * v_est / 15.0;

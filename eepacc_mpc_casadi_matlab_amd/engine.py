@@ -275,6 +275,36 @@ def RunOpt_ABMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = No
     return sol
 
 
+def RunOpt_BLMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = None, device: int = 0) -> Dict[str, Any]:
+    """optSol = RunOpt_BLMPC(OPTsettings)  -- ABO/RunOpt_BLMPC.m:1, the baseline controller, single ego vehicle.
+
+    Takes the same OPTsettings as the other controllers (the BL_* fields and W_BL select horizon, estimator and
+    weights, settings.Settings_BL) and returns the optSol fields of :318-345."""
+    from .settings import SetVehicleParameters, Settings_BL
+    if V is None:
+        V = SetVehicleParameters(OPTsettings.get("tree", "ABO"))
+    BL = Settings_BL(OPTsettings)
+    eng = Engine(BL, V, device=device, max_batch=1)
+    t = eng.torch
+    Ts = float(BL["Tvec"][0])
+    n_steps = int(round(OPTsettings["t_sim"] / Ts)) + 1
+    s_tv = np.asarray(OPTsettings["s_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
+    v_tv = np.asarray(OPTsettings["v_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
+    traj, status = eng.run_abmpc([OPTsettings["s_init"]], [OPTsettings["v_init"]], [OPTsettings["a_minus1"]], s_tv, v_tv)
+    rpm, Tm, P, E = eng.postprocess(traj)
+    t.cuda.synchronize()
+    tr = traj.cpu().numpy()[:, :, 0]
+    sol: Dict[str, Any] = {}
+    for name, key in (("s", "s_opt"), ("v", "v_opt"), ("Fm", "Fm_opt"), ("Fb", "Fb_opt"), ("xi_f", "xi_f_opt"),
+                      ("a", "a_opt"), ("cost", "cost")):
+        sol[key] = tr[:, OUT[name]].copy()
+    sol["exitMessage"] = status.cpu().numpy()[:, 0].astype(np.float64)
+    sol["rpm_opt"] = rpm.cpu().numpy()[:, 0]; sol["Tm_opt"] = Tm.cpu().numpy()[:, 0]
+    sol["P_opt"] = P.cpu().numpy()[:, 0]; sol["E_opt"] = E.cpu().numpy()[:, 0]
+    sol["j_opt"] = np.diff(sol["a_opt"]) / Ts
+    return sol
+
+
 def RunOpt_FBMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = None, device: int = 0) -> Dict[str, Any]:
     """optSol = RunOpt_FBMPC(OPTsettings)  -- ABO/RunOpt_FBMPC.m:1, single ego vehicle.
 

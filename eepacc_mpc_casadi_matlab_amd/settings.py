@@ -239,6 +239,7 @@ def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 
     else:                  # ORIG/Settings.m:48-62 (6 weights)
         w_c, w_v, w_h, w_f = 0.1, 8e5, 1e4, 1e10
         OPT["W_AB"] = 1e-3 * np.array([w_c * 3e5, w_c * 1e7, w_v, w_h, w_f * 9e0, w_f])
+    OPT["W_BL"] = np.array([1e2, 0.0, 0.0, 1e7])                             # :66-71 [w_v, w_a, w_j, w_f]
     Ts = OPT["Ts"]
     OPT.update(s_init=0.0, v_init=0 / 3.6, a_minus1=0.0)                     # :85-87
     OPT["FBuseTaylor"] = True                                                # :98
@@ -259,6 +260,8 @@ def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 
         OPT.setdefault("cutOffDist", 3.5e3)
     else:
         OPT = GetUseCase(OPT)                                                # :195-198
+    OPT.update(BL_a_LimLowVel=3.0, BL_a_LimHighVel=2.0, BL_j_LimLowVel=3.0, BL_j_LimHighVel=1.5,
+               BL_N_hor=OPT["N_hor"], BL_Ts=Ts, BL_trajEstSett=1)            # :131-139
     OPT.update(h_min=2.0, tau_min=0.5)                                       # :203-204
     OPT.update(TVlength=4.0, TVinitDist=10.0, TVinitVel=0.0, TV_N_hor=20, TV_Ts=0.5)  # :207-212
     OPT.update(stopVel=0.2, stopRefDist=100.0, stopRefVelSlope=1.0, TLStopRegionSize=2.0,
@@ -282,6 +285,17 @@ def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 
     OPT["Mb"] = Mb
     OPT["stopRefvelIncr"] = OPT["stopRefDist"] * OPT["stopRefVelSlope"]
     return GenerateUseCase(OPT)
+
+
+def Settings_BL(OPT: Dict[str, Any]) -> Dict[str, Any]:
+    """The view of OPTsettings that RunOpt_BLMPC takes (ABO/RunOpt_BLMPC.m:17-21, CreateQP_BL.m:26-33,
+    EstimateVehicleTrajectory.m:25-29): horizon BL_N_hor with the uniform step BL_Ts, ego estimator BL_trajEstSett,
+    weights W_BL, baseline comfort limits.  bl_mode = 1 selects CreateQP_BL behind the ABMPC entry points."""
+    B = dict(OPT)
+    N = int(OPT["BL_N_hor"])
+    B.update(bl_mode=1, N_hor=N, Tvec=float(OPT["BL_Ts"]) * np.ones(N), Mb=np.zeros(N, dtype=np.int32),
+             paramEstSetting=int(OPT["BL_trajEstSett"]))
+    return B
 
 
 def Run_DrivingCycle(OPT: Dict[str, Any], V_TO_10Hz: np.ndarray | None = None,

@@ -94,6 +94,25 @@ typedef struct eepacc_settings {
     int32_t n_stop;      const double* stopLoc;
     int32_t n_TL;        const double* TLLoc;      /* [n_TL][4] row-major: loc,phase,red,green */
     double  stopRefDist, stopRefVelSlope, stopVel, TLstopVel, TLStopRegionSize, alpha_TTL;
+    /* Baseline controller (ABO/RunOpt_BLMPC.m, ABO/Functions/MPCs/CreateQP_BL.m).  bl_mode = 1 makes a handle
+     * a RunOpt_BLMPC: the ABMPC entry points (eepacc_ab_step, eepacc_run_abmpc, ...) then pose CreateQP_BL's problem
+     * (n_u = 2: a, xi_f; one slack for all soft rows; objective -w_v sum v_k + w_a a^2 + w_j jerk^2 + w_f xi_f) with
+     * the baseline comfort limits of EstimateRouteAndComfortBounds.m:173-189 (MPCtype 1).  The caller passes
+     * N_hor = BL_N_hor, Tvec[k] = BL_Ts and paramEstSetting = BL_trajEstSett (ABO/Settings.m:137-139,
+     * EstimateVehicleTrajectory.m:25-29); W_AB / W_FB are ignored.  W_BL = [w_v, w_a, w_j, w_f] (ABO/Settings.m:66-71).
+     * With the reference's weights (w_a = w_j = 0) the problem is a linear program; the curvature bl_lp_eps
+     * (<= 0: 1e-4) is added to its Hessian, which leaves the solution at the LP's (least-norm) optimum
+     * (DESIGN.md section 3.7). */
+    int32_t bl_mode, bl_pad;
+    double  W_BL[4];
+    double  BL_a_LimLowVel, BL_a_LimHighVel, BL_j_LimLowVel, BL_j_LimHighVel;   /* ABO/Settings.m:131-134 */
+    double  bl_lp_eps;
+    /* ABMPC / baseline controller: a measured state that violates its own hard bounds (s_0 >= 0, 0 <= v_0 <= v_max,
+     * CreateQP_AB.m:256-261, CreateQP_BL.m:214-222) by more than this makes the step infeasible (status 1).
+     * <= 0: 1e-9 (baseline controller: 1e-7), which lets the closed loop's rounding noise at standstill through (the
+     * saved ABMPC solutions have exitMessage = 0 there); 1e-11 reproduces the three bad exits of the saved baseline
+     * solution (v_0 = -3e-10). */
+    double  state_bound_tol;
 } eepacc_settings;
 
 typedef struct eepacc_handle eepacc_handle;

@@ -132,6 +132,16 @@ void orc_estimate_route_and_comfort_bounds(const eepacc_settings* S, const doubl
                 }
             }
         }
+        if (S->bl_mode) {                       /* baseline limits :173-189 (MPCtype 1) */
+            double aL = S->BL_a_LimLowVel, aH = S->BL_a_LimHighVel, jL = S->BL_j_LimLowVel, jH = S->BL_j_LimHighVel, a, j;
+            if (v_est[i] < 5.0) { a = aL; j = jL; }
+            else if (v_est[i] < 20.0) {
+                a = (4.0 * aL - aH) / 3.0 + (aH - aL) / 15.0 * v_est[i];
+                j = (4.0 * jL - jH) / 3.0 + (jH - jL) / 15.0 * v_est[i];
+            } else { a = aH; j = jH; }
+            a_min_est[i] = -a; a_max_est[i] = a; j_min_est[i] = -j; j_max_est[i] = j;
+            continue;
+        }
         /* ISO limits :157-171 */
         if (v_est[i] < 5.0) {
             a_min_est[i] = -5.0; a_max_est[i] = 4.0; j_min_est[i] = -5.0; j_max_est[i] = 5.0;
@@ -262,6 +272,77 @@ void orc_create_qp_ab(const eepacc_settings* S, const eepacc_vehicle* V, double 
         SETG(o + scurr, 1.0); SETG(o + vcurr, S->tau_min); ROW_END(-INFINITY, s_tv_est[N - 1]);
     }
     if (r != nC) { fprintf(stderr, "orc_create_qp_ab: row count %d != %d\n", r, nC); abort(); }
+}
+
+/* ABO/Functions/MPCs/CreateQP_BL.m:36-334, solverToUse == 1 branch (dense qpOASES: no dynamics rows, z = [s v a xi_f]) */
+int orc_bl_num_rows(const eepacc_settings* S) { return 13 * S->N_hor + 2; }
+
+void orc_create_qp_bl(const eepacc_settings* S, const eepacc_vehicle* V, double s_0, double v_0,
+                      const double* s_est, const double* v_est, const double* s_tv_est, double t_0,
+                      double a_minus1, double* H, double* c, double* G, double* g_lb, double* g_ub) {
+    (void)s_0; (void)v_0;
+    const int N = S->N_hor, n_x = 2, n_u = 2, n_x_u = n_x + n_u;
+    const int nz = n_x_u * N + n_x;
+    const int nC = orc_bl_num_rows(S);
+    const double w_v = S->W_BL[0], w_a = S->W_BL[1], w_j = S->W_BL[2], w_f = S->W_BL[3];   /* :36-39 */
+    const double Ts = S->Tvec[0];                                                          /* :30 */
+    double sl[EEPACC_MAX_HORIZON], v_lim[EEPACC_MAX_HORIZON], v_stop[EEPACC_MAX_HORIZON],
+        v_TL[EEPACC_MAX_HORIZON], v_curv[EEPACC_MAX_HORIZON], a_min[EEPACC_MAX_HORIZON],
+        a_max[EEPACC_MAX_HORIZON], j_min[EEPACC_MAX_HORIZON], j_max[EEPACC_MAX_HORIZON];
+    orc_estimate_route_and_comfort_bounds(S, s_est, v_est, t_0, sl, v_lim, v_stop, v_TL, v_curv,
+                                          a_min, a_max, j_min, j_max);          /* :44 (MPCtype 1) */
+    memset(H, 0, sizeof(double) * (size_t)nz * nz);
+    memset(c, 0, sizeof(double) * nz);
+    memset(G, 0, sizeof(double) * (size_t)nC * nz);
+    const double s_min = 0.0, s_max = S->s_goal, v_min = 0.0, v_max = V->v_max;  /* :58-62 */
+    const int scurr = 0, vcurr = 1, acurr = 2, aprev = 2 - n_x_u, xi_f = 3;      /* :112-118, 0-based */
+    int r = 0;
+    for (int kk = 0; kk < N; ++kk) {
+        const int o = kk * n_x_u;
+        c[o + vcurr] -= w_v;                                                     /* :133 */
+        H[IDX(o + acurr, o + acurr, nz)] += 2.0 * w_a;                           /* :136-137 */
+        if (kk == 0) {                                                           /* :140-147 */
+            H[IDX(o + acurr, o + acurr, nz)] += 2.0 * w_j / (Ts * Ts);
+            c[o + acurr] -= 2.0 * w_j / Ts * a_minus1;
+        } else {
+            double q = 2.0 * w_j / (Ts * Ts);
+            H[IDX(o + acurr, o + acurr, nz)] += q;
+            H[IDX(o + acurr, o + aprev, nz)] -= q;
+            H[IDX(o + aprev, o + acurr, nz)] -= q;
+            H[IDX(o + aprev, o + aprev, nz)] += q;
+        }
+        c[o + xi_f] += w_f;                                                      /* :150 */
+        /* bounds as rows :214-227 */
+        SETG(o + scurr, 1.0); ROW_END(s_min, s_max);
+        SETG(o + vcurr, 1.0); ROW_END(v_min, v_max);
+        SETG(o + xi_f, 1.0);  ROW_END(0.0, INFINITY);
+        /* acceleration :231-238 */
+        SETG(o + acurr, 1.0); SETG(o + xi_f, 1.0);  ROW_END(a_min[kk], INFINITY);
+        SETG(o + acurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, a_max[kk]);
+        /* jerk :241-261 */
+        if (kk > 0) {
+            SETG(o + aprev, -1.0); SETG(o + acurr, 1.0); SETG(o + xi_f, 1.0);  ROW_END(Ts * j_min[kk], INFINITY);
+            SETG(o + aprev, -1.0); SETG(o + acurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, Ts * j_max[kk]);
+        } else {
+            SETG(o + acurr, 1.0); SETG(o + xi_f, 1.0);  ROW_END(Ts * j_min[kk] + a_minus1, INFINITY);
+            SETG(o + acurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, Ts * j_max[kk] + a_minus1);
+        }
+        /* speed limit, curve, stop, traffic light :264-288 */
+        SETG(o + vcurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, v_lim[kk]);
+        SETG(o + vcurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, v_curv[kk]);
+        SETG(o + vcurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, v_stop[kk]);
+        SETG(o + vcurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, v_TL[kk]);
+        /* safe headway :291-298 */
+        SETG(o + scurr, 1.0); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, s_tv_est[kk] - S->h_min);
+        SETG(o + scurr, 1.0); SETG(o + vcurr, S->tau_min); SETG(o + xi_f, -1.0); ROW_END(-INFINITY, s_tv_est[kk]);
+    }
+    {   /* final stage :303-318 (s_tv_est(N), MATLAB 1-based) */
+        const int o = N * n_x_u;
+        c[o + vcurr] -= w_v;
+        SETG(o + scurr, 1.0); ROW_END(-INFINITY, s_tv_est[N - 1] - S->h_min);
+        SETG(o + scurr, 1.0); SETG(o + vcurr, S->tau_min); ROW_END(-INFINITY, s_tv_est[N - 1]);
+    }
+    if (r != nC) { fprintf(stderr, "orc_create_qp_bl: row count %d != %d\n", r, nC); abort(); }
 }
 
 /* ABO/Functions/MPCs/CreateQP_FB.m:158-489, solverToUse == 1 branch */
@@ -617,8 +698,10 @@ static void ab_force_allocation(const eepacc_settings* S, const eepacc_vehicle* 
 /* One ABMPC step: ABO/RunOpt_ABMPC.m:193-329 */
 int orc_ab_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_step_io* io,
                 double* dense_out) {
-    const int N = S->N_hor, nu = 5, nx = 2;
-    const int nz = N * (nx + nu) + nx, nV = N * nu, nC = orc_ab_num_rows(S);
+    /* bl_mode: the same loop body is ABO/RunOpt_BLMPC.m:175-300 with n_u = 2 and CreateQP_BL */
+    const int bl = S->bl_mode != 0;
+    const int N = S->N_hor, nu = bl ? 2 : 5, nx = 2;
+    const int nz = N * (nx + nu) + nx, nV = N * nu, nC = bl ? orc_bl_num_rows(S) : orc_ab_num_rows(S);
     double s_est[EEPACC_MAX_HORIZON + 1], v_est[EEPACC_MAX_HORIZON + 1];
     double s_tv_est[EEPACC_MAX_HORIZON + 1], v_tv_est[EEPACC_MAX_HORIZON + 1];
     /* :194,197 (paramEstSetting 2 would need the previous solution: io->s_pred/v_pred in) */
@@ -639,7 +722,8 @@ int orc_ab_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_step_io* 
     double* x = (double*)calloc(nV, sizeof(double));
     double* z = (double*)malloc(sizeof(double) * nz);
     double A[EEPACC_MAX_HORIZON * 4], Bm[EEPACC_MAX_HORIZON * 2 * 5], Dm[EEPACC_MAX_HORIZON * 2];
-    orc_create_qp_ab(S, V, io->s, io->v, s_est, v_est, s_tv_est, io->t0, io->a_prev, Hs, cs, Gs, glb, gub); /* :204 */
+    if (bl) orc_create_qp_bl(S, V, io->s, io->v, s_est, v_est, s_tv_est, io->t0, io->a_prev, Hs, cs, Gs, glb, gub);
+    else orc_create_qp_ab(S, V, io->s, io->v, s_est, v_est, s_tv_est, io->t0, io->a_prev, Hs, cs, Gs, glb, gub); /* :204 */
     memset(Bm, 0, sizeof(Bm));
     for (int k = 0; k < N; ++k) {                                            /* :74-82 */
         double T = S->Tvec[k];
@@ -651,7 +735,18 @@ int orc_ab_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_step_io* 
     orc_transform_to_dense(N, nu, nC, A, Bm, Dm, Hs, cs, Gs, glb, gub, io->s, io->v, Hd, cd, Gd,
                            lbd, ubd, Psi, d);                                 /* :238 */
     double cost = 0.0;
+    double bl_eps = 0.0;
+    if (bl && S->W_BL[1] == 0.0 && S->W_BL[2] == 0.0) {
+        /* the reference's baseline weights make this a linear program (H = 0), which qpOASES regularises internally.
+         * Here: curvature eps on the accelerations (the least-norm LP optimum for eps below a data-dependent
+         * threshold); the slack columns keep the solver's own relative floor.  eps is taken out of the cost again. */
+        bl_eps = S->bl_lp_eps > 0.0 ? S->bl_lp_eps : 1e-4;
+        for (int k = 0; k < N; ++k) Hd[IDX(k * nu, k * nu, nV)] += bl_eps;
+    }
     orc_qp_solve_dense(nV, nC, Hd, cd, Gd, lbd, ubd, NULL, NULL, NULL, 0.0, 0, x, &cost, &io->qp); /* :252 */
+    if (bl_eps > 0.0) {
+        for (int k = 0; k < N; ++k) { cost -= 0.5 * bl_eps * x[k * nu] * x[k * nu]; Hd[IDX(k * nu, k * nu, nV)] -= bl_eps; }
+    }
     for (int i = 0; i < nz; ++i) {                                           /* :261 */
         double sacc = d[i];
         for (int j = 0; j < nV; ++j) sacc += Psi[IDX(i, j, nV)] * x[j];
@@ -665,10 +760,10 @@ int orc_ab_step(const eepacc_settings* S, const eepacc_vehicle* V, orc_step_io* 
     io->out[EEPACC_OUT_FM] = Fm;
     io->out[EEPACC_OUT_FB] = Fb;
     io->out[EEPACC_OUT_A] = a_real;
-    io->out[EEPACC_OUT_XI_V] = z[3];
-    io->out[EEPACC_OUT_XI_H] = z[4];
-    io->out[EEPACC_OUT_XI_S] = z[5];
-    io->out[EEPACC_OUT_XI_F] = z[6];
+    io->out[EEPACC_OUT_XI_V] = bl ? 0.0 : z[3];
+    io->out[EEPACC_OUT_XI_H] = bl ? 0.0 : z[4];
+    io->out[EEPACC_OUT_XI_S] = bl ? 0.0 : z[5];
+    io->out[EEPACC_OUT_XI_F] = bl ? z[3] : z[6];                               /* BL :252 */
     io->out[EEPACC_OUT_COST] = cost;
     io->out[EEPACC_OUT_DISTHOR] = s_est[N] - io->s;                           /* :200 */
     io->out[EEPACC_OUT_AQP] = z[2];

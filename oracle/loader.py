@@ -61,6 +61,7 @@ class Oracle:
         L = self.lib
         L.orc_ab_num_rows.argtypes = [C.POINTER(SettingsPOD)]
         L.orc_fb_num_rows.argtypes = [C.POINTER(SettingsPOD)]
+        L.orc_bl_num_rows.argtypes = [C.POINTER(SettingsPOD)]
         L.orc_ab_step.argtypes = [C.POINTER(SettingsPOD), C.POINTER(Vehicle), C.POINTER(StepIO), c_double_p]
         L.orc_fb_step.argtypes = [C.POINTER(SettingsPOD), C.POINTER(Vehicle), C.POINTER(LoopState),
                                   C.POINTER(StepIO), c_double_p]
@@ -81,10 +82,14 @@ class Oracle:
 
     # sizes --------------------------------------------------------------------------------
     def nC(self, kind="ab"):
+        if kind == "ab" and self.S.bl_mode:
+            return int(self.lib.orc_bl_num_rows(C.byref(self.S)))
         f = self.lib.orc_ab_num_rows if kind == "ab" else self.lib.orc_fb_num_rows
         return int(f(C.byref(self.S)))
 
     def nV(self, kind="ab"):
+        if kind == "ab" and self.S.bl_mode:
+            return self.N * 2                      # baseline controller: a, xi_f
         return self.N * (5 if kind == "ab" else 6)
 
     # one open-loop step ----------------------------------------------------------------------

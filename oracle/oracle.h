@@ -45,10 +45,16 @@ void orc_estimate_route_and_comfort_bounds(const eepacc_settings* S, const doubl
 
 /* number of constraint rows of the trimmed sparse-form QP / variables */
 int orc_ab_num_rows(const eepacc_settings* S);
+int orc_bl_num_rows(const eepacc_settings* S);      /* ABO/Functions/MPCs/CreateQP_BL.m, dense form: 13 N + 2 */
 int orc_fb_num_rows(const eepacc_settings* S);
 
 /* A4: ABO/Functions/MPCs/CreateQP_AB.m:58-387 (solverToUse == 1), rows already trimmed as
  * ABO/RunOpt_ABMPC.m:229-233 does.  H[nz][nz], c[nz], G[nC][nz], row-major, nz = 7N+2. */
+/* ABO/Functions/MPCs/CreateQP_BL.m:36-334 (baseline controller; S->bl_mode = 1 makes orc_ab_step / orc_run_abmpc the
+ * loop of ABO/RunOpt_BLMPC.m) */
+void orc_create_qp_bl(const eepacc_settings* S, const eepacc_vehicle* V, double s_0, double v_0,
+                      const double* s_est, const double* v_est, const double* s_tv_est, double t_0,
+                      double a_minus1, double* H, double* c, double* G, double* g_lb, double* g_ub);
 void orc_create_qp_ab(const eepacc_settings* S, const eepacc_vehicle* V, double s_0, double v_0,
                       const double* s_est, const double* v_est, const double* s_tv_est, double t_0,
                       double a_minus1, double* H, double* c, double* G, double* g_lb, double* g_ub);

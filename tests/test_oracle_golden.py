@@ -187,3 +187,29 @@ def test_fb_closed_loop_871_steps(tree):
     assert np.abs(F - G["Fm_opt"] - G["Fb_opt"]).max() < 1e-7          # measured 2.7e-9 N
     assert np.abs(ref[1:, OUT["Fm"]] - G["Fm_opt"][1:]).max() < 1e-7
     assert np.abs(ref[1:, OUT["Fb"]] - G["Fb_opt"][1:]).max() < 1e-7
+
+
+@pytest.mark.parametrize("tree", ["ABO", "ORIG"])
+def test_bl_oracle_against_saved_solution(tree):
+    """Baseline controller (RunOpt_BLMPC / CreateQP_BL): the oracle's dense G equals the saved one entry for entry, the
+    saved H is zero (a linear program with the reference's W_BL), and from the saved states the oracle reproduces the
+    saved forces on every third step to qpOASES' accuracy and the saved exit flags (k = 6, 7, 8: v = -3e-10 at
+    standstill makes the hard row v_0 >= 0 infeasible).  k = 41 has a face of optima (parity undefined, excluded)."""
+    from oracle.loader import Oracle
+    from eepacc_mpc_casadi_matlab_amd.settings import Settings_BL
+    OPT, V, s_tv, v_tv = make_case(tree, 20)
+    G = load_golden(f"{tree.lower()}_blmpc")
+    orc = Oracle(Settings_BL(OPT), V)
+    r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, 870), want_dense=True)
+    assert np.abs(G["H"]).max() == 0.0 and np.abs(r["H"]).max() == 0.0
+    assert r["G"].shape == G["G"].shape and np.abs(r["G"] - G["G"]).max() == 0.0
+    bad = []
+    for k in list(range(0, 871, 3)) + [7, 8]:
+        r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, k))
+        if r["status"] != 0:
+            bad.append(k)
+            continue
+        if k == 41:
+            continue
+        assert abs(r["out"][OUT["Fm"]] - G["Fm_opt"][k]) < 2e-4 and abs(r["out"][OUT["Fb"]] - G["Fb_opt"][k]) < 2e-4, k
+    assert sorted(bad) == [6, 7, 8] == list(np.where(G["exitMessage"] != 0)[0])

@@ -1,0 +1,53 @@
+"""Baseline controller diagnostics: open-loop outliers against the saved solution and the oracle, S2 instance flags."""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import make_case, load_golden, golden_step_inputs
+from oracle import Oracle
+from eepacc_mpc_casadi_matlab_amd.engine import Engine
+from eepacc_mpc_casadi_matlab_amd._abi import OUT
+from eepacc_mpc_casadi_matlab_amd.settings import Settings_BL
+from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
+OPT, V, s_tv, v_tv = make_case("ABO", 20)
+G = load_golden("abo_blmpc")
+BL = Settings_BL(OPT)
+eng = Engine(BL, V, device=0, max_batch=1024)
+orc = Oracle(BL, V)
+inps = [golden_step_inputs(G, s_tv, v_tv, k) for k in range(871)]
+c = {nm: np.array([d[nm] for d in inps]) for nm in ("s", "v", "a_prev", "t0", "s_tv", "v_tv", "a_tv_prev")}
+out, sp, vp, status = eng.ab_step(**c)
+o = out.cpu().numpy(); st = status.cpu().numpy()
+d = np.abs(o[OUT["Fm"]] - G["Fm_opt"]) + np.abs(o[OUT["Fb"]] - G["Fb_opt"])
+print("status != 0 at", np.where(st != 0)[0])
+top = np.argsort(-d)[:8]
+for k in top:
+    r = orc.ab_step(**inps[k])
+    print("k", k, "gpu-golden", d[k], "orc-golden", abs(r["out"][OUT["Fm"]] - G["Fm_opt"][k]), "gpu a", o[OUT["AQP" if "AQP" in OUT else "a"], k], "orc a", r["out"][11], "iters", int(eng.last_iterations(871)[k]) if hasattr(eng, "last_iterations") else -1)
+OPT30, V, _, _ = make_case("ABO", 30)
+BL30 = Settings_BL(OPT30)
+lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
+sc = make_s2(8, 60, lead["V_TO_2Hz"])
+e2 = Engine(BL30, V, device=0, max_batch=8)
+traj, status = e2.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+tr = traj.cpu().numpy(); st = status.cpu().numpy()
+o30 = Oracle(BL30, V)
+for i in range(8):
+    ref, rst, _ = o30.run("ab", 60, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+    print("inst", i, "gpu bad", np.where(st[:, i] != 0)[0][:8], "orc bad", np.where(rst != 0)[0][:8])
+    bad = (rst != 0) | (st[:, i] != 0)
+    n = int(np.argmax(bad)) if bad.any() else 60
+    print("   first", n, "v there gpu %.3e orc %.3e s gpu %.3e orc %.3e" % (tr[min(n, 59), OUT["v"], i], ref[min(n, 59), OUT["v"]], tr[min(n, 59), OUT["s"], i], ref[min(n, 59), OUT["s"]]),
+          "max diffs before:", {nm: float(np.abs(tr[:n, OUT[nm], i] - ref[:n, OUT[nm]]).max()) if n else 0.0 for nm in ("s", "v", "Fm", "xi_f")})
+e3 = Engine(BL, V, device=0, max_batch=4)
+traj, status = e3.run_abmpc(np.zeros(1), np.zeros(1), np.zeros(1), s_tv[:871, None].copy(), v_tv[:871, None].copy())
+tr = traj.cpu().numpy()[:, :, 0]; st = status.cpu().numpy()[:, 0]
+ref, rst, _ = orc.run("ab", 871, 0.0, 0.0, 0.0, s_tv[:871].copy(), v_tv[:871].copy())
+print("closed loop: gpu bad", np.where(st != 0)[0], "orc bad", np.where(rst != 0)[0])
+for nm in ("s", "v", "a", "Fm", "Fb", "xi_f"):
+    dg = np.abs(tr[:41, OUT[nm]] - G[nm + "_opt"][:41]).max() if nm + "_opt" in G.files else float("nan")
+    print(nm, "vs golden (first 41)", dg, "vs golden all", np.abs(tr[:, OUT[nm]] - G[nm + "_opt"]).max() if nm + "_opt" in G.files else None, "vs oracle all", np.abs(tr[:, OUT[nm]] - ref[:, OUT[nm]]).max())
+bad = np.where(st != 0)[0]
+print("bad steps", bad)
+for k in bad[:20]:
+    print("  k", k, "v %.3e s %.6f a_prev %.3e Fm %.4f  | orc v %.3e Fm %.4f | lead gap %.4f v_tv %.4f" % (tr[k, OUT["v"]], tr[k, OUT["s"]], (tr[k, OUT["v"]] - tr[k - 1, OUT["v"]]) / 0.5, tr[k, OUT["Fm"]], ref[k, OUT["v"]], ref[k, OUT["Fm"]], s_tv[k] - tr[k, OUT["s"]], v_tv[k]))
