@@ -27,6 +27,8 @@ mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray* mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char** fieldnames);
 int mxAddField(mxArray* pm, const char* fieldname);
 int mxGetFieldNumber(const mxArray* pm, const char* fieldname);
+mxArray* mxGetFieldByNumber(const mxArray* pm, mwIndex index, int fieldnumber);
+void mxRemoveField(mxArray* pm, int fieldnumber);
 void mxSetField(mxArray* pm, mwIndex index, const char* fieldname, mxArray* pvalue);
 void mxDestroyArray(mxArray* pm);
 void* mxMalloc(size_t n);

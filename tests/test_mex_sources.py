@@ -1,4 +1,4 @@
-"""The MEX gateways mex/RunOpt_ABMPC.c and mex/RunOpt_FBMPC.c (level B1) are a source
+"""The MEX gateways mex/RunOpt_ABMPC.c, mex/RunOpt_FBMPC.c and mex/RunOpt_BLMPC.c (level B1) are a source
 deliverable: MATLAB exists neither here nor on the GPU box.  What can be checked without it: they are complete,
 warning-free C against the MEX API's signatures (tests/mexstub/mex.h holds declarations only), they bind exactly
 the host entry points of include/eepacc.h, read every OPTsettings field the reference reads on this path and write
@@ -14,7 +14,7 @@ from conftest import ROOT
 MEX = os.path.join(ROOT, "mex")
 
 
-@pytest.mark.parametrize("src", ["RunOpt_ABMPC.c", "RunOpt_FBMPC.c"])
+@pytest.mark.parametrize("src", ["RunOpt_ABMPC.c", "RunOpt_FBMPC.c", "RunOpt_BLMPC.c"])
 def test_gateway_compiles_against_the_mex_api(src, tmp_path):
     obj = tmp_path / (src + ".o")
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-c", os.path.join(MEX, src), "-o", str(obj),
@@ -22,7 +22,7 @@ def test_gateway_compiles_against_the_mex_api(src, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True).stdout
-    entry = "eepacc_run_abmpc_host" if "AB" in src else "eepacc_run_fbmpc_host"
+    entry = "eepacc_run_fbmpc_host" if "FB" in src else "eepacc_run_abmpc_host"      # BLMPC: a bl_mode handle behind the AB entry
     for need in ("eepacc_create", "eepacc_destroy", "eepacc_last_error", entry, "mexCallMATLAB", "mexErrMsgIdAndTxt"):
         assert re.search(r"\b%s\b" % need, syms), need
     assert "mexFunction" in subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout
@@ -46,3 +46,14 @@ def test_gateway_reads_and_writes_the_reference_fields():
            "j_opt", "Tm_opt", "rpm_opt", "tLoop", "tSolve", "H", "G", "DistHor", "exitMessage", "solverTime",
            "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f", "cost_P"}
     assert out <= written, out - written
+
+
+def test_baseline_gateway_reads_its_own_settings():
+    """RunOpt_BLMPC.c: the BL_* fields and W_BL of ABO/Settings.m:66-71,131-139 select horizon, estimator, weights and
+    comfort limits (RunOpt_BLMPC.m:17-20, CreateQP_BL.m:27-39, EstimateRouteAndComfortBounds.m:41-46)."""
+    src = open(os.path.join(MEX, "RunOpt_BLMPC.c")).read()
+    read = set(re.findall(r'emx_(?:scalar|vector)\(O, "(\w+)"', src))
+    assert {"BL_N_hor", "BL_trajEstSett", "W_BL", "BL_a_LimLowVel", "BL_a_LimHighVel", "BL_j_LimLowVel", "BL_j_LimHighVel"} <= read
+    assert "bl_mode = 1" in src and "eepacc_run_abmpc_host" in src
+    for f in ("xi_v_opt", "DistHor"):                    # not part of RunOpt_BLMPC's optSol (:318-345)
+        assert '"%s"' % f in src
