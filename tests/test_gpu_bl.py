@@ -145,3 +145,21 @@ def test_bl_s2_batch_vs_oracle(torch_mod, lead_trace):
         if d["s"] < 1e-5 and d["v"] < 1e-5 and d["Fm"] < 5e-2 and d["Fb"] < 5e-2:
             agree += 1
     assert agree >= 6, agree
+
+
+def test_runopt_blmpc_mirror_returns_the_reference_struct(torch_mod):
+    """optSol = RunOpt_BLMPC(OPTsettings): field names of ABO/RunOpt_BLMPC.m:233-234,318-345 and the saved values up to
+    the saved solution's degenerate step."""
+    from eepacc_mpc_casadi_matlab_amd.engine import RunOpt_BLMPC
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    OPT = dict(OPT); OPT["s_tv"] = s_tv; OPT["v_tv"] = v_tv
+    G = load_golden("abo_blmpc")
+    sol = RunOpt_BLMPC(OPT, V)
+    k0 = min(DEGENERATE)
+    for key in ("s_opt", "v_opt", "Fm_opt", "Fb_opt", "a_opt", "P_opt", "E_opt", "Tm_opt", "rpm_opt", "j_opt"):
+        ref = np.asarray(G[key], dtype=np.float64).ravel()
+        got = np.asarray(sol[key]).ravel()
+        assert got.shape == ref.shape, key
+        n = k0 - 1
+        assert np.abs(got[:n] - ref[:n]).max() <= 1e-6 * max(1.0, np.abs(ref[:n]).max()), key
+    assert sol["exitMessage"].shape == (871,) and sol["exitMessage"].sum() == 0
