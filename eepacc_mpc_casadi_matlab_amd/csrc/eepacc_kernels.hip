@@ -43,12 +43,14 @@ namespace eepacc {
 
 // working-set capacity: rigid rows are linearly independent, so m <= N (+ terminal rows)
 constexpr int kMMaxSmall = 34, kNSSmall = 32;     // N <= 32: 8 waves / CU (4 per block, 2 blocks)
-// N <= 63: 60 KB of LDS per wave (He 32 KB, P 17.7 KB), 2 waves per CU.  Trading working-set capacity for occupancy
-// does not work: with a capacity of 50 rigid rows (3 waves per CU; -DEEPACC_MMAX_LARGE=50 -DEEPACC_WPB_LARGE=3) the S2
+// N <= 63: 44.6 KB of LDS per wave (He packed 16.6 KB, P 17.7 KB), 3 waves per CU (round 2: a full He of 32 KB allowed 2).
+// Trading working-set capacity for more does not work: with a capacity of 50 rigid rows (-DEEPACC_MMAX_LARGE=50) the S2
 // workload at N = 60 overflows the working set on 15 % of the steps (measured), so the full N + 2 stays.
 #ifndef EEPACC_MMAX_LARGE
 #define EEPACC_MMAX_LARGE 66
-#define EEPACC_WPB_LARGE 2
+#endif
+#ifndef EEPACC_WPB_LARGE
+#define EEPACC_WPB_LARGE 3
 #endif
 constexpr int kMMaxLarge = EEPACC_MMAX_LARGE, kNSLarge = 64, kWpbLarge = EEPACC_WPB_LARGE;
 constexpr int kChunkStepsDefault = nomb::kChunkStepsDefault;
