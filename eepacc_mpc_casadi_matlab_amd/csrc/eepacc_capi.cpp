@@ -59,6 +59,7 @@ struct eepacc_handle {
     // FBMPC state (allocated on first use)
     int fb_B = 0, fb_chunk = 0;
     int fb_k_done = 0;
+    bool fb_by_step = false;                 // the FB step counter was advanced by eepacc_fb_step (no closed-loop carry to resume from)
     double *fb_H = nullptr, *fb_g = nullptr, *fb_A = nullptr, *fb_lba = nullptr, *fb_uba = nullptr;   // [fb_chunk]
     double *fb_x = nullptr, *fb_x0 = nullptr, *fb_cost = nullptr, *fb_meas = nullptr, *fb_carry = nullptr;   // [fb_B]
     double *fb_A22 = nullptr, *fb_D2 = nullptr;
@@ -342,7 +343,7 @@ extern "C" int eepacc_reset(eepacc_handle* h) {
     HIPCHK(hipMemset(h->d_pred, 0, (size_t)h->max_batch * 128 * sizeof(double)));
     HIPCHK(hipMemset(h->d_err, 0, sizeof(int)));
     h->k_done = 0; h->carry_B = 0;
-    h->fb_k_done = 0;
+    h->fb_k_done = 0; h->fb_by_step = false;
     if (h->fbs_state) HIPCHK(hipMemset(h->fbs_state, 0, (size_t)h->max_batch * eepacc::kFbsStateDoubles * sizeof(double)));
     if (h->fb_x0) HIPCHK(hipMemset(h->fb_x0, 0, (size_t)h->fb_B * 6 * h->cfg.N * sizeof(double)));
     if (h->fb_sp) {
@@ -503,7 +504,7 @@ static int fb_prepare(eepacc_handle* h, int B) {
     HIPCHK(hipMemset(h->fb_sp, 0, nB * (N + 1) * sizeof(double)));
     HIPCHK(hipMemset(h->fb_vp, 0, nB * (N + 1) * sizeof(double)));
     h->fb_B = B; h->fb_chunk = (int)chunk;
-    h->fb_k_done = 0;
+    h->fb_k_done = 0; h->fb_by_step = false;
     return EEPACC_OK;
 }
 
@@ -570,9 +571,10 @@ extern "C" int eepacc_fb_step(eepacc_handle* h, int B, const double* s, const do
         a.state = h->fbs_state; a.hb = h->fbs_hb; a.out = out; a.s_pred = s_pred; a.v_pred = v_pred;
         a.status = status; a.iters = h->d_iters;
         HIPCHK(eepacc::launch_fbs_step(a, h->cfg.N, (hipStream_t)stream));
-        h->fb_k_done += 1; h->last_B = B;
+        h->fb_k_done += 1; h->last_B = B; h->fb_by_step = true;
         return EEPACC_OK;
     }
+    h->fb_by_step = true;
     int rc = fb_prepare(h, B);
     if (rc != EEPACC_OK) return rc;
     return fb_one_step(h, B, 0, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, out, s_pred, v_pred, status, (hipStream_t)stream);
@@ -589,6 +591,8 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
     HIPCHK(hipSetDevice(h->device));
     if (h->fb_k_done > 0 && B != h->last_B)
         return fail(EEPACC_EINVAL, "eepacc_run_fbmpc: B changed while resuming; call eepacc_reset first");
+    if (h->fb_k_done > 0 && h->fb_by_step)
+        return fail(EEPACC_EINVAL, "eepacc_run_fbmpc after eepacc_fb_step: the per-step operator keeps no closed-loop state to resume from; call eepacc_reset first");
     if (h->fbs) {
         // work-unit length: 16 MPC steps, shorter for short launches so that every resident wave still gets several units
         int chunk_steps = eepacc::pick_chunk_steps(n_steps, B, h->num_cus * 6);

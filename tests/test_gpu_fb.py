@@ -260,6 +260,10 @@ def test_fb_step_operator_vs_oracle(torch_mod):
         assert np.abs(sp.cpu().numpy()[:, 0] - r["s_pred"]).max() < 1e-7
         assert np.abs(vp.cpu().numpy()[:, 0] - r["v_pred"]).max() < 1e-7
         assert np.abs(o[:, 0] - o[:, 1]).max() == 0.0
+    # the per-step operator keeps no closed-loop carry: resuming a closed loop after it is refused, not run on stale state
+    from eepacc_mpc_casadi_matlab_amd.engine import EepaccError
+    with pytest.raises(EepaccError, match="eepacc_reset"):
+        eng.run_fbmpc(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros((3, 2)), np.zeros((3, 2)), resume=True)
 
 
 def test_fb_batch_properties(torch_mod, lead_trace):
