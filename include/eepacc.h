@@ -109,7 +109,7 @@ typedef struct eepacc_settings {
     double  bl_lp_eps;
     /* ABMPC / baseline controller: a measured state that violates its own hard bounds (s_0 >= 0, 0 <= v_0 <= v_max,
      * CreateQP_AB.m:256-261, CreateQP_BL.m:214-222) by more than this makes the step infeasible (status 1).
-     * <= 0: 1e-9 (baseline controller: 1e-7), which lets the closed loop's rounding noise at standstill through (the
+     * <= 0: 1e-9 (baseline controller: 1e-5 m/s), which lets the closed loop's rounding noise at standstill through (the
      * saved ABMPC solutions have exitMessage = 0 there); 1e-11 reproduces the three bad exits of the saved baseline
      * solution (v_0 = -3e-10). */
     double  state_bound_tol;
