@@ -42,7 +42,11 @@
 namespace eepacc {
 
 // working-set capacity: rigid rows are linearly independent, so m <= N (+ terminal rows)
-constexpr int kMMaxSmall = 34, kNSSmall = 32;     // N <= 32: 8 waves / CU (4 per block, 2 blocks)
+#ifndef EEPACC_MMAX_SMALL
+#define EEPACC_MMAX_SMALL 34
+#endif
+constexpr int kMMaxSmall = EEPACC_MMAX_SMALL, kNSSmall = 32;     // N <= 32: 8 waves / CU (4 per block, 2 blocks)
+constexpr int kBlocksSmall = kMMaxSmall <= 32 ? 3 : 2;
 // N <= 63: 44.6 KB of LDS per wave (He packed 16.6 KB, P 17.7 KB), 3 waves per CU (round 2: a full He of 32 KB allowed 2).
 // Trading working-set capacity for more does not work: with a capacity of 50 rigid rows (-DEEPACC_MMAX_LARGE=50) the S2
 // workload at N = 60 overflows the working set on 15 % of the steps (measured), so the full N + 2 stays.
@@ -113,7 +117,7 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, int variant, int B, int k_s
         e = hipMemsetAsync(iters_total, 0, sizeof(int32_t) * (size_t)B, stream);
         if (e != hipSuccess) return e;
     }
-    const int kChunkSteps = pick_chunk_steps(n_steps, B, num_cus * (N > kNSSmall ? kWpbLarge : 8));
+    const int kChunkSteps = pick_chunk_steps(n_steps, B, num_cus * (N > kNSSmall ? kWpbLarge : 4 * kBlocksSmall));
     // bound of the inter-unit spin wait (a debug hook lowers it to exercise the failure path)
     int spin_limit = 1 << 26;
     if (const char* ev = getenv("EEPACC_DEBUG_SPIN_LIMIT")) spin_limit = atoi(ev);
@@ -124,7 +128,7 @@ hipError_t launch_run_abmpc(const DevCfg* dC, int N, int variant, int B, int k_s
         if (grid > need) grid = need;
         EEPACC_LAUNCH(k_run_abmpc, kMMaxLarge, kNSLarge, kWpbLarge, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
     } else {
-        int grid = num_cus * 2, need = (n_units + 3) / 4;
+        int grid = num_cus * kBlocksSmall, need = (n_units + 3) / 4;
         if (grid > need) grid = need;
         EEPACC_LAUNCH(k_run_abmpc, kMMaxSmall, kNSSmall, 4, grid, dC, B, k_start, n_steps, s0, v0, a_m1, s_tv, v_tv, carry, codes, traj, status, iters_total, work_counter, done, kChunkSteps, err_word, spin_limit);
     }
