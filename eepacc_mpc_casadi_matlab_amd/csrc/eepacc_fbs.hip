@@ -1453,6 +1453,25 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
         L.valid = valid;
         so.status = __any(infeasible_const) ? 1 : 0;
     }
+    // Feasibility of the hard rows, decided before the solve.  Only the bounds on s_k, v_k, the force bounds and the two
+    // terminal headway rows have no slack (CreateQP_FB.m:311-326,476-489).  v_{k+1} = A22_k v_k + beta_k u_k + D2_k and
+    // s_{k+1} = s_k + T_k v_k are monotone in u, so braking as hard as the force bounds allow without letting v drop
+    // below zero gives the smallest reachable s_N and v_N at once: if even that violates a terminal row the QP has no
+    // solution (a lead vehicle too close to stop behind).  A dual active set needs its whole iteration budget to find
+    // that out; decided here, the step costs nothing, reports status 1 like the reference and applies full braking.
+    bool hopeless = false;
+    {
+        double vmin = in.v, smin = in.s;
+        const double umin = -2e4;                         // Fm >= -1e4 and Fb >= -1e4 (b[F_FMLO], b[F_FBLO] above)
+        for (int k = 0; k < N; ++k) {
+            const double ak = bcast(a22, k), dk = bcast(d2, k), Tk = bcast(L.T, k);
+            smin += Tk * vmin;
+            vmin = fmax(ak * vmin + dk + Tk / lm * umin, 0.0);
+        }
+        const double over = fmax(smin - (stv_Nm1 - C.h_min), smin + c.tau_min * vmin - stv_Nm1);
+        hopeless = over > 1e-6 * (1.0 + fabs(stv_Nm1));
+        if (hopeless) so.status = 1;
+    }
     L.ign = 0u;
     L.code = code;
 #pragma unroll
@@ -1470,7 +1489,7 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     for (int _i = 0; _i < 16; ++_i) _fp[_i] = 0;
 #endif
     // iteration cap: a cold solve needs about 1.5 N working-set changes; beyond 6 N + 60 the solve is cycling (status 1)
-    if (!h_bad) st = solve_qp<MMAX, NS>(L, c, M, Hs, Hb, 6 * N + 60, grad_total);
+    if (!h_bad && !hopeless) st = solve_qp<MMAX, NS>(L, c, M, Hs, Hb, 6 * N + 60, grad_total);
     code = L.code;
 #ifdef EEPACC_FBS_DEBUG
     if (lane <= N) printf("FIN lane %d code %llx u %.15e ign %x valid %x st %d iters %d m %d\n", lane, L.code, L.u, L.ign, L.valid, st.status, st.iters, st.m);
@@ -1512,6 +1531,7 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
         // plant state stays finite whatever the iterate was
         Fm0 = (Fm0 == Fm0) ? fmin(fmax(Fm0, -1e4), 1e4) : 0.0;
         Fb0 = (Fb0 == Fb0) ? fmin(fmax(Fb0, -1e4), 0.0) : 0.0;
+        if (hopeless) { Fm0 = in.v > 1e-3 ? -1e4 : 0.0; Fb0 = Fm0; }     // no solve was run: brake as hard as the bounds allow
     }
     so.out[EEPACC_OUT_FM] = Fm0;
     so.out[EEPACC_OUT_FB] = Fb0;
@@ -1524,6 +1544,14 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     so.out[EEPACC_OUT_DISTHOR] = dist_hor;
     so.out[EEPACC_OUT_AQP] = 0.0;
     if (st.status != 0) so.status = 1;
+    if (so.status != 0) {
+        // a failed step may sit on a physically meaningless measured state (negative speed after earlier failures): its
+        // slack and cost read-outs carry no information; they are reported as zero rather than as inf / NaN
+        for (int f = EEPACC_OUT_XI_V; f <= EEPACC_OUT_COST; ++f) {
+            const double x = so.out[f];
+            if (!(fabs(x) < 1e300)) so.out[f] = 0.0;
+        }
+    }
     so.iters = st.iters;
 #ifdef EEPACC_FBS_TIMING
     _ft = wall_clock64() - 0;   // output phase is measured from the end of the solve by the caller's next step; negligible
