@@ -59,7 +59,7 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
     dt_all = time.perf_counter() - t1
     return dict(value=done / dt, unit="QP steps/s", cores=1, kind="port",
                 sample="%d S2 instances x %d closed-loop %sMPC steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
-                       % (n_inst, n_steps, kind.upper(), OPT["N_hor"]),
+                       % (n_inst, n_steps, "BL" if OPT.get("bl_mode") else kind.upper(), OPT["N_hor"]),
                 all_cores={"value": done_all / dt_all, "cores": cores,
                            "sample": "%d instances x %d steps, one instance per thread" % (n_all, n_steps)})
 
@@ -76,8 +76,9 @@ def profile_figures(fb: bool, N: int):
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["abmpc", "fbmpc"], default="abmpc",
-                    help="abmpc: the headline (BASELINE.json configs[1]); fbmpc: configs[2], same contract")
+    ap.add_argument("--workload", choices=["abmpc", "fbmpc", "blmpc"], default="abmpc",
+                    help="abmpc: the headline (BASELINE.json configs[1]); fbmpc: configs[2]; blmpc: the baseline controller "
+                         "(RunOpt_BLMPC, a handle with bl_mode = 1); same contract")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096)
@@ -118,9 +119,13 @@ def run_bench(args, make_engine=None, device=None, backend=None):
         else:
             dist.init_process_group(backend)
     fb = args.workload == "fbmpc"
+    bl = args.workload == "blmpc"
     K, W = args.steps, args.warmup
     N, B = args.horizon, args.batch
     OPT, V, _, _ = make_case("ABO", N)
+    if bl:
+        from eepacc_mpc_casadi_matlab_amd.settings import Settings_BL
+        OPT = Settings_BL(OPT)
     Ts = float(OPT["Tvec"][0])
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
     lo, _ = shard_range(rank, world, B)                                  # rank r owns instances [rB, (r+1)B)
@@ -207,13 +212,13 @@ def run_bench(args, make_engine=None, device=None, backend=None):
     if rank == 0:
         total_steps = world * B * K
         value = total_steps / dt
-        nV, nC = (6 * N, 26 * N + 2) if fb else (5 * N, 14 * N + 2)
+        nV, nC = (6 * N, 26 * N + 2) if fb else ((2 * N, 13 * N + 2) if bl else (5 * N, 14 * N + 2))
         bytes_mat = 8 * (nV * nV + nC * nV + 3 * nV + 2 * nC) + 8 * (nV + 1)     # SURVEY 8d, R-materialised
         bytes_fused = 152                                                          # SURVEY 8d, R-fused (compulsory)
         launch_s = (kernel_ms / 1e3) / launches
         qp_per_launch = B * (K / launches)
         qp_rate = qp_per_launch / launch_s                                         # QP steps/s of this rank's kernel
-        prof, prof_path = profile_figures(fb, N)
+        prof, prof_path = profile_figures(fb, N) if not bl else (None, "none: the baseline variant is not profiled separately")
         kname = "k_fbs_run" if fb else "k_run_abmpc"
         if prof is not None:
             ps = prof["per_qp_step"]
@@ -239,12 +244,12 @@ def run_bench(args, make_engine=None, device=None, backend=None):
                     "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3}
         it_step = float(iters.mean()) / max(K / launches, 1)
         res = {
-            "metric": "QP steps/sec (whole node), %s N=%d dense QP at batch %d" % ("FBMPC" if fb else "ABMPC", N, B),
+            "metric": "QP steps/sec (whole node), %s N=%d dense QP at batch %d" % ("FBMPC" if fb else ("BLMPC" if bl else "ABMPC"), N, B),
             "value": value, "unit": "QP steps/s", "n_gpus": min(world, n_dev) if on_gpu else 0, "ranks": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s N=%d fp64, batch=%d synthetic S2 ego/lead scenarios per GPU, closed loop"
-                                   % ("FBMPC" if fb else "ABMPC", N, B),
+                                   % ("FBMPC" if fb else ("BLMPC (baseline controller, LP)" if bl else "ABMPC"), N, B),
                        "batch_per_gpu": B, "horizon": N, "steps_per_launch": int(K / launches),
                        "parallelism": "instances sharded across %d GPU(s), no data-path collective" % world},
             "roofline": roof,

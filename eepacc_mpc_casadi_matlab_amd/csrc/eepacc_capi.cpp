@@ -160,6 +160,11 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     C.state_tol = S->state_bound_tol > 0.0 ? S->state_bound_tol : (S->bl_mode ? 1e-5 : 1e-9);
     double bl_travel = 0.0;
     if (S->bl_mode) {
+        // the LP needs about 13 working-set changes per warm step and 3N from cold (871 saved steps at N = 20 as cold QPs:
+        // mean 58, 99th percentile 113, maximum 270); a solve that is still going after 15N + 60 is cycling on a degenerate
+        // vertex and is cut off there
+        C.max_iter = 15 * N + 60;
+        if (const char* ev = getenv("EEPACC_DEBUG_BL_MAX_ITER")) C.max_iter = atoi(ev);
         // RunOpt_BLMPC: CreateQP_BL.m:36-39,131-148  W_BL = [w_v (travel incentive), w_a, w_j, w_f]
         if (S->bl_mode != 1) return fail(EEPACC_EINVAL, "bl_mode must be 0 or 1");
         if (C.mb_any) return fail(EEPACC_ENOTSUP, "the baseline controller has no move blocking (RunOpt_BLMPC.m)");
