@@ -1022,6 +1022,11 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         // blocking events per (lane, type / local variable)
         double t1 = kInf; int ev = 0x7fffffff;
         {
+            // candidate step lengths num / den (den > 0) are compared cross-multiplied against the lane's best so far
+            // (t1n / t1d): one division per lane at the end instead of one per candidate
+            double t1n = kInf, t1d = 1.0;
+#define EEPACC_CAND(NUM, DEN, EVCODE) do { const double _n = (NUM), _d = (DEN); \
+                if (_n * t1d < t1n * _d) { t1n = _n; t1d = _d; ev = (EVCODE); } } while (0)
             LocalSums S{0, 0, 0, 0, 0, 0, 0, 0};
             int pos = L.base;
 #pragma unroll
@@ -1031,10 +1036,10 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                 const double l = M.lam[pos], r = M.rv[pos];
                 ++pos;
                 if (g2 == GH) {
-                    if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
-                    else if (r < 0.0) { double tt = fmax(c.wH - l, 0.0) / (-r); if (tt < t1) { t1 = tt; ev = (EV_COMPL << 16) | (lane << 5) | t; } }
+                    if (r > 0.0) EEPACC_CAND(fmax(l, 0.0), r, (EV_DROP << 16) | (lane << 5) | t);
+                    else if (r < 0.0) EEPACC_CAND(fmax(c.wH - l, 0.0), -r, (EV_COMPL << 16) | (lane << 5) | t);
                 } else {
-                    if (r > 0.0) { double tt = fmax(l, 0.0) / r; if (tt < t1) { t1 = tt; ev = (EV_DROP << 16) | (lane << 5) | t; } }
+                    if (r > 0.0) EEPACC_CAND(fmax(l, 0.0), r, (EV_DROP << 16) | (lane << 5) | t);
                     if (g2 == GF) { S.LF += l; S.RF -= r; } else if (g2 == GS) { S.LS += l; S.RS -= r; } else if (g2 == GV) { S.LV += l; S.RV -= r; }
                     if (lane < N) { const double aw = row_aw(t, c); S.LW += aw * l; S.RW -= aw * r; }
                 }
@@ -1071,22 +1076,21 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
                     const double val = g2 == GF ? Mu.vF : (g2 == GS ? Mu.vS : (g2 == GV ? Mu.vV : Mu.vW));
                     const double rate = g2 == GF ? Mu.rF : (g2 == GS ? Mu.rS : (g2 == GV ? Mu.rV : Mu.rW));
                     if (rate < 0.0) {
-                        const double tt = fmax(val, 0.0) / (-rate);
-                        if (tt < t1) { t1 = tt; ev = (EV_CAP << 16) | (lane << 5) | g2; }
+                        EEPACC_CAND(fmax(val, 0.0), -rate, (EV_CAP << 16) | (lane << 5) | g2);
                     }
                 }
             }
             if (lane == kq && !q.is_bound && q.gq == GH) {
-                double tt = fmax(c.wH - lam_q, 0.0);
-                if (tt < t1) { t1 = tt; ev = (EV_CAPIN << 16) | (lane << 5); }
+                EEPACC_CAND(fmax(c.wH - lam_q, 0.0), 1.0, (EV_CAPIN << 16) | (lane << 5));
             }
             if (lane == kq && q.is_bound && q.gq == GH) {
                 const double xi_now = L.lbH - viol, den = 1.0 - c.qH * zz;
                 if (den > 0.0) {
-                    double tt = fmax(c.wH + c.qH * xi_now - lam_q, 0.0) / den;
-                    if (tt < t1) { t1 = tt; ev = (EV_DROPH << 16) | (lane << 5) | F_HWP; }
+                    EEPACC_CAND(fmax(c.wH + c.qH * xi_now - lam_q, 0.0), den, (EV_DROPH << 16) | (lane << 5) | F_HWP);
                 }
             }
+#undef EEPACC_CAND
+            t1 = (ev == 0x7fffffff) ? kInf : t1n / t1d;
             wave_argmin(t1, ev);
         }
         const double tstep = fmin(t1, t2);
