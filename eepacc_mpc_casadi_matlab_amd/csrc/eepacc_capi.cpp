@@ -667,6 +667,31 @@ static int run_host(eepacc_handle* h, bool fb, int B, int n_steps, const double*
     return rc;
 }
 
+// RunOpt_BLMPC by name: the ABMPC entry points on a handle that was created as the baseline controller
+static int need_bl(const eepacc_handle* h) {
+    if (!h) return fail(EEPACC_EINVAL, "NULL handle");
+    if (!h->cfg.bl_mode) return fail(EEPACC_EINVAL, "this handle was not created with bl_mode = 1 (RunOpt_BLMPC)");
+    return EEPACC_OK;
+}
+extern "C" int eepacc_bl_step(eepacc_handle* h, int B, const double* s, const double* v, const double* a_prev,
+                              const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                              double* out, double* s_pred, double* v_pred, int32_t* status, void* stream) {
+    const int rc = need_bl(h);
+    return rc != EEPACC_OK ? rc : eepacc_ab_step(h, B, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, out, s_pred, v_pred, status, stream);
+}
+extern "C" int eepacc_run_blmpc(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                const double* a_minus1, const double* s_tv, const double* v_tv, double* traj,
+                                int32_t* status, void* stream) {
+    const int rc = need_bl(h);
+    return rc != EEPACC_OK ? rc : eepacc_run_abmpc(h, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status, stream);
+}
+extern "C" int eepacc_run_blmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
+                                     const double* a_minus1, const double* s_tv, const double* v_tv,
+                                     double* traj, int32_t* status) {
+    const int rc = need_bl(h);
+    return rc != EEPACC_OK ? rc : run_host(h, false, B, n_steps, s0, v0, a_minus1, s_tv, v_tv, traj, status);
+}
+
 extern "C" int eepacc_run_abmpc_host(eepacc_handle* h, int B, int n_steps, const double* s0, const double* v0,
                                      const double* a_minus1, const double* s_tv, const double* v_tv,
                                      double* traj, int32_t* status) {

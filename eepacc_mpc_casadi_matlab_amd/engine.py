@@ -47,6 +47,9 @@ def load_library() -> C.CDLL:
     lib.eepacc_ab_step.argtypes = [vp, C.c_int] + [dp] * 7 + [dp, dp, dp, dp, vp]
     lib.eepacc_run_abmpc.argtypes = [vp, C.c_int, C.c_int] + [dp] * 5 + [dp, dp, vp]
     lib.eepacc_run_abmpc_host.argtypes = [vp, C.c_int, C.c_int] + [c_double_p] * 5 + [c_double_p, ip]
+    lib.eepacc_bl_step.argtypes = lib.eepacc_ab_step.argtypes
+    lib.eepacc_run_blmpc.argtypes = lib.eepacc_run_abmpc.argtypes
+    lib.eepacc_run_blmpc_host.argtypes = lib.eepacc_run_abmpc_host.argtypes
     lib.eepacc_postprocess.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, vp]
     lib.eepacc_last_iterations.argtypes = [vp, C.c_int, ip]
     lib.eepacc_fb_step.argtypes = [vp, C.c_int] + [dp] * 10 + [dp, dp, dp, dp, vp]
@@ -61,7 +64,8 @@ def load_library() -> C.CDLL:
 
 ABI_SYMBOLS = ["eepacc_last_error", "eepacc_version", "eepacc_sizeof_settings", "eepacc_sizeof_vehicle", "eepacc_create", "eepacc_destroy", "eepacc_reset",
                "eepacc_ab_step", "eepacc_run_abmpc", "eepacc_fb_step", "eepacc_run_fbmpc",
-               "eepacc_run_abmpc_host", "eepacc_run_fbmpc_host", "eepacc_postprocess",
+               "eepacc_run_abmpc_host", "eepacc_run_fbmpc_host", "eepacc_bl_step", "eepacc_run_blmpc", "eepacc_run_blmpc_host",
+               "eepacc_postprocess",
                "eepacc_last_iterations", "eepacc_qp_solve_batched", "eepacc_synchronize", "eepacc_build_flags"]
 
 
@@ -125,7 +129,7 @@ class Engine:
         return out, sp, vp, status
 
     # B1 ------------------------------------------------------------------------------------
-    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False, out=None):
+    def run_abmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False, out=None, by_name_bl: bool = False):
         """s_tv, v_tv: [n_steps, B] lead traces.  Returns traj [n_steps, OUT_N, B], status [n_steps, B].
         resume=True continues the simulation of the previous call (s_tv/v_tv hold the next rows).
         out=(traj, status): preallocated output tensors to write into."""
@@ -142,9 +146,14 @@ class Engine:
         else:
             traj = t.empty((n_steps, OUT_N, B), dtype=t.float64, device=self.device)
             status = t.empty((n_steps, B), dtype=t.int32, device=self.device)
-        _check(self.lib.eepacc_run_abmpc(self.h, B, n_steps, *[x.data_ptr() for x in ins], s_tv.data_ptr(),
-                                         v_tv.data_ptr(), traj.data_ptr(), status.data_ptr(), self._stream()))
+        f = self.lib.eepacc_run_blmpc if by_name_bl else self.lib.eepacc_run_abmpc
+        _check(f(self.h, B, n_steps, *[x.data_ptr() for x in ins], s_tv.data_ptr(),
+                 v_tv.data_ptr(), traj.data_ptr(), status.data_ptr(), self._stream()))
         return traj, status
+
+    def run_blmpc(self, s0, v0, a_minus1, s_tv, v_tv, resume: bool = False, out=None):
+        """eepacc_run_blmpc: run_abmpc on a handle created from settings.Settings_BL (refused on any other handle)."""
+        return self.run_abmpc(s0, v0, a_minus1, s_tv, v_tv, resume=resume, out=out, by_name_bl=True)
 
     # FBMPC: same two operators (ABO/RunOpt_FBMPC.m:161-331) -----------------------------------
     def fb_step(self, s, v, v_prev, a_prev, Fm_prev, Fb_prev, t0, s_tv, v_tv, a_tv_prev, want_pred: bool = True):
@@ -290,7 +299,7 @@ def RunOpt_BLMPC(OPTsettings: Dict[str, Any], V: Optional[Dict[str, float]] = No
     n_steps = int(round(OPTsettings["t_sim"] / Ts)) + 1
     s_tv = np.asarray(OPTsettings["s_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
     v_tv = np.asarray(OPTsettings["v_tv"], dtype=np.float64).reshape(-1)[:n_steps].reshape(n_steps, 1)
-    traj, status = eng.run_abmpc([OPTsettings["s_init"]], [OPTsettings["v_init"]], [OPTsettings["a_minus1"]], s_tv, v_tv)
+    traj, status = eng.run_blmpc([OPTsettings["s_init"]], [OPTsettings["v_init"]], [OPTsettings["a_minus1"]], s_tv, v_tv)
     rpm, Tm, P, E = eng.postprocess(traj)
     t.cuda.synchronize()
     tr = traj.cpu().numpy()[:, :, 0]

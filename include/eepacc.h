@@ -214,6 +214,24 @@ int  eepacc_run_fbmpc_host(eepacc_handle* h, int B, int n_steps,
                            const double* s_tv, const double* v_tv,
                            double* traj, int32_t* status);
 
+/* Baseline controller by name: optSol = RunOpt_BLMPC(OPTsettings) (ABO/RunOpt_BLMPC.m:1, ABO/Main.m:97) and the body of
+ * its loop (:175-300).  Same arguments, outputs and error behaviour as eepacc_ab_step / eepacc_run_abmpc /
+ * eepacc_run_abmpc_host; they require a handle created with bl_mode = 1 (EEPACC_EINVAL otherwise), so a binding for
+ * RunOpt_BLMPC cannot silently run the ABMPC problem.  The xi_v, xi_h, xi_s entries of the output block are zero
+ * (the baseline QP has the one slack xi_f). */
+int  eepacc_bl_step(eepacc_handle* h, int B,
+                    const double* s, const double* v, const double* a_prev, const double* t0,
+                    const double* s_tv, const double* v_tv, const double* a_tv_prev,
+                    double* out, double* s_pred, double* v_pred, int32_t* status, void* stream);
+int  eepacc_run_blmpc(eepacc_handle* h, int B, int n_steps,
+                      const double* s0, const double* v0, const double* a_minus1,
+                      const double* s_tv, const double* v_tv,
+                      double* traj, int32_t* status, void* stream);
+int  eepacc_run_blmpc_host(eepacc_handle* h, int B, int n_steps,
+                           const double* s0, const double* v0, const double* a_minus1,
+                           const double* s_tv, const double* v_tv,
+                           double* traj, int32_t* status);
+
 /* Post-processing of a closed-loop trajectory (ABO/RunOpt_ABMPC.m:343-349): rpm, Tm,
  * fifth-order battery power P and cumulative energy E, all device [n_steps][B]. */
 int  eepacc_postprocess(eepacc_handle* h, int B, int n_steps, const double* traj,

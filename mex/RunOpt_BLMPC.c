@@ -2,7 +2,7 @@
  * RunOpt_BLMPC.c -- MEX gateway: optSol = RunOpt_BLMPC(OPTsettings)      (ABO/RunOpt_BLMPC.m:1, ABO/Main.m:97)
  * Drop-in for the baseline controller's closed loop; see eepacc_mex_common.h for the contract and the build line
  *     mex -I../include RunOpt_BLMPC.c -L../eepacc_mpc_casadi_matlab_amd -leepacc
- * The baseline controller runs behind the ABMPC entry points of a handle created with bl_mode = 1 (include/eepacc.h):
+ * The baseline controller is a handle created with bl_mode = 1, run through eepacc_run_blmpc_host (include/eepacc.h):
  * horizon BL_N_hor with the uniform step Tvec(1) (RunOpt_BLMPC.m:17,20), ego estimator BL_trajEstSett
  * (EstimateVehicleTrajectory.m:25-29), weights W_BL (CreateQP_BL.m:36-39), comfort limits BL_*_Lim*Vel
  * (EstimateRouteAndComfortBounds.m:41-46).
@@ -48,7 +48,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double* traj = (double*)mxMalloc(sizeof(double) * (size_t)ns * EEPACC_OUT_N);
     int32_t* status = (int32_t*)mxMalloc(sizeof(int32_t) * (size_t)ns);
     const clock_t c0 = clock();
-    const int rc = eepacc_run_abmpc_host(g_handle, 1, ns, &in.s_init, &in.v_init, &in.a_minus1, in.s_tv, in.v_tv, traj, status);
+    const int rc = eepacc_run_blmpc_host(g_handle, 1, ns, &in.s_init, &in.v_init, &in.a_minus1, in.s_tv, in.v_tv, traj, status);
     const double wall = (double)(clock() - c0) / CLOCKS_PER_SEC;
     at_exit();
     if (rc != EEPACC_OK) mexErrMsgIdAndTxt("eepacc:run", "%s", eepacc_last_error());

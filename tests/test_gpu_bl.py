@@ -215,3 +215,18 @@ def test_bl_reference_use_cases(case, torch_mod):
     assert np.isfinite(tr).all()
     assert int((status.cpu().numpy() != 0).sum()) <= (3 if case == 10 else 0)
     assert np.abs(tr[:, OUT["s"]] - ref[:, OUT["s"]]).max() < 5.0 and np.abs(tr[:, OUT["v"]] - ref[:, OUT["v"]]).max() < 2.0, case
+
+
+def test_bl_entry_points_by_name(torch_mod):
+    """eepacc_run_blmpc / eepacc_bl_step: the baseline controller by name; refused on a handle that is not one."""
+    from eepacc_mpc_casadi_matlab_amd.engine import EepaccError
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    n = 40
+    stv = s_tv[:n, None].copy(); vtv = v_tv[:n, None].copy()
+    bl = _engine(Settings_BL(OPT), V, 2)
+    t1, s1 = bl.run_blmpc(np.zeros(1), np.zeros(1), np.zeros(1), stv, vtv)
+    t2, s2 = bl.run_abmpc(np.zeros(1), np.zeros(1), np.zeros(1), stv, vtv)
+    assert np.array_equal(t1.cpu().numpy(), t2.cpu().numpy()) and np.array_equal(s1.cpu().numpy(), s2.cpu().numpy())
+    ab = _engine(OPT, V, 2)
+    with pytest.raises(EepaccError, match="bl_mode"):
+        ab.run_blmpc(np.zeros(1), np.zeros(1), np.zeros(1), stv, vtv)

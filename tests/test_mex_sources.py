@@ -22,7 +22,7 @@ def test_gateway_compiles_against_the_mex_api(src, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True).stdout
-    entry = "eepacc_run_fbmpc_host" if "FB" in src else "eepacc_run_abmpc_host"      # BLMPC: a bl_mode handle behind the AB entry
+    entry = {"RunOpt_ABMPC.c": "eepacc_run_abmpc_host", "RunOpt_FBMPC.c": "eepacc_run_fbmpc_host", "RunOpt_BLMPC.c": "eepacc_run_blmpc_host"}[src]
     for need in ("eepacc_create", "eepacc_destroy", "eepacc_last_error", entry, "mexCallMATLAB", "mexErrMsgIdAndTxt"):
         assert re.search(r"\b%s\b" % need, syms), need
     assert "mexFunction" in subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout
@@ -54,6 +54,6 @@ def test_baseline_gateway_reads_its_own_settings():
     src = open(os.path.join(MEX, "RunOpt_BLMPC.c")).read()
     read = set(re.findall(r'emx_(?:scalar|vector)\(O, "(\w+)"', src))
     assert {"BL_N_hor", "BL_trajEstSett", "W_BL", "BL_a_LimLowVel", "BL_a_LimHighVel", "BL_j_LimLowVel", "BL_j_LimHighVel"} <= read
-    assert "bl_mode = 1" in src and "eepacc_run_abmpc_host" in src
+    assert "bl_mode = 1" in src and "eepacc_run_blmpc_host" in src
     for f in ("xi_v_opt", "DistHor"):                    # not part of RunOpt_BLMPC's optSol (:318-345)
         assert '"%s"' % f in src
