@@ -46,6 +46,22 @@ def extract(path, var, out_name):
     print(out_name, {k: v.shape for k, v in d.items() if k in ("s_opt", "H", "G")})
 
 
+NLP_FIELDS = ["s_velInc", "v_velInc", "s_opt", "v_opt", "theta_opt", "j_opt", "Fm_opt", "Fb_opt", "xi_v_opt",
+              "xi_h_opt", "xi_s_opt", "xi_f_opt", "P_opt", "E_opt", "a_opt", "Tm_opt", "rpm_opt", "tSolve",
+              "cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f"]
+
+
+def extract_nlp(path, out_name):
+    """optSol of ABO/RunOpt_NLP.m:512-605 as saved by ABO/Main.m:125 (IPOPT's solution of the
+    870-interval multiple-shooting problem; exitMessage is the string 'Solve_Succeeded')."""
+    m = sio.loadmat(path, squeeze_me=True, struct_as_record=False)
+    sol = m["NLPsol"]
+    d = {f: np.asarray(getattr(sol, f), dtype=np.float64).ravel() for f in NLP_FIELDS}
+    d["solve_succeeded"] = np.array([1.0 if str(sol.exitMessage) == "Solve_Succeeded" else 0.0])
+    np.savez_compressed(os.path.join(OUT, out_name), **d)
+    print(out_name, d["s_opt"].shape, str(sol.exitMessage))
+
+
 def lead_trace():
     m = sio.loadmat(os.path.join(ABO, "DrivingCycles", "TO01_EAD.mat"), squeeze_me=True)
     V_TO = np.asarray(m["V_TO"], dtype=np.float64).ravel()
@@ -78,6 +94,8 @@ def main():
     extract(os.path.join(ORIG, "savedBLMPCsol.mat"), "BLMPCsol", "orig_blmpc.npz")
     extract(os.path.join(ORIG, "savedABMPCsol.mat"), "ABMPCsol", "orig_abmpc.npz")
     extract(os.path.join(ORIG, "savedFBMPCsol.mat"), "FBMPCsol", "orig_fbmpc.npz")
+    extract_nlp(os.path.join(ABO, "savedNLPsol.mat"), "abo_nlp.npz")
+    extract_nlp(os.path.join(ORIG, "savedNLPsol.mat"), "orig_nlp.npz")
     lead_trace()
     argonne_lead()
 
