@@ -34,6 +34,7 @@ using eepacc::DevCfg;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+namespace eepacc { int set_error(int code, const std::string& msg) { return fail(code, msg); } }   // other translation units (eepacc_nlp.hip)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(EEPACC_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct eepacc_handle {

@@ -1,0 +1,338 @@
+// Batched function evaluator of the full-route problem of RunOpt_NLP (include/eepacc_nlp.h).
+//
+// One thread per (route, interval): index = k*B + i, so every load and store is unit-stride across the
+// routes of a wavefront.  Per thread: the RK4 x 4 integrator of ABO/RunOpt_NLP.m:262-278 on (s, v) and on the
+// running cost, carried as first-order forward-mode jets over (v_k, theta_k, F_k = Fm_k + Fb_k) so that the
+// objective gradient and the integrator's Jacobian block come out of the same pass; then the rows of
+// :357-501 in the reference's order.  Roofline: fp64 vector ALU (a few kflop against 0.5 KB per thread).
+// The objective is reduced per route by a second kernel in a fixed order (bit-reproducible).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eepacc_nlp.h"
+
+namespace eepacc { int set_error(int code, const std::string& msg); }
+
+namespace {
+
+struct NlpDev {
+    int N, n_tl, flat, R, has_goal;
+    double Ts, W[7], b[21], s_goal, h_min, tau_min, alpha, Fm_min, Fm_max;
+    eepacc_vehicle V;
+    int n_vlim, n_curv, n_slope, n_stop, n_vinc;
+    int o_vlim, o_curv, o_slope, o_stop, o_vinc, o_tls, o_tlstate;   // offsets into the table blob (knots, then values)
+    double tl_v[3];
+};
+
+struct Tab { const double* x; const double* y; int n; };
+
+__device__ __forceinline__ void pwa(const Tab t, double x, double& val, double& slope) {
+    int i = 0;
+    for (int q = 1; q < t.n - 1; ++q) i = (t.x[q] <= x) ? q : i;     // last knot <= x, clipped to [0, n-2]
+    const double dx = t.x[i + 1] - t.x[i];
+    slope = dx > 0.0 ? (t.y[i + 1] - t.y[i]) / dx : 0.0;
+    val = t.y[i] + slope * (x - t.x[i]);
+}
+
+// The speed along the interval depends on (v_k, theta_k, F_k) only; the motor force Fm_k enters the running cost
+// alone.  So the sensitivities are carried as 3-direction jets (value + d/dv_k, d/dtheta_k, d/dF_k) and the power
+// polynomial contributes through its two scalar partials.
+struct J3 {
+    double v, g[3];
+};
+__device__ __forceinline__ J3 axpy(double c, const J3& a, const J3& b) {      // c*a + b
+    return J3{fma(c, a.v, b.v), {fma(c, a.g[0], b.g[0]), fma(c, a.g[1], b.g[1]), fma(c, a.g[2], b.g[2])}};
+}
+
+// RunOpt_NLP.m:226-231: P(Fm, r) with its partials dP/dFm, dP/dr
+__device__ __forceinline__ void p_bat(const double* b, double F, double r, double& P, double& PF, double& Pr) {
+    const double F2 = F * F, F3 = F2 * F, F4 = F2 * F2, r2 = r * r, r3 = r2 * r, r4 = r2 * r2;
+    P = b[0] + b[1] * F + b[2] * r + b[3] * F2 + b[4] * F * r + b[5] * r2 + b[6] * F3 + b[7] * F2 * r + b[8] * F * r2 + b[9] * r3
+      + b[10] * F4 + b[11] * F3 * r + b[12] * F2 * r2 + b[13] * F * r3 + b[14] * r4
+      + b[15] * F4 * F + b[16] * F4 * r + b[17] * F3 * r2 + b[18] * F2 * r3 + b[19] * F * r4 + b[20] * r4 * r;
+    PF = b[1] + 2.0 * b[3] * F + b[4] * r + 3.0 * b[6] * F2 + 2.0 * b[7] * F * r + b[8] * r2 + 4.0 * b[10] * F3 + 3.0 * b[11] * F2 * r
+       + 2.0 * b[12] * F * r2 + b[13] * r3 + 5.0 * b[15] * F4 + 4.0 * b[16] * F3 * r + 3.0 * b[17] * F2 * r2 + 2.0 * b[18] * F * r3 + b[19] * r4;
+    Pr = b[2] + b[4] * F + 2.0 * b[5] * r + b[7] * F2 + 2.0 * b[8] * F * r + 3.0 * b[9] * r2 + b[11] * F3 + 2.0 * b[12] * F2 * r
+       + 3.0 * b[13] * F * r2 + 4.0 * b[14] * r3 + b[16] * F4 + 2.0 * b[17] * F3 * r + 3.0 * b[18] * F2 * r2 + 4.0 * b[19] * F * r3 + 5.0 * b[20] * r4;
+}
+
+__global__ void __launch_bounds__(256)
+k_nlp_eval(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ s_tv,
+           const double* __restrict__ X, const double* __restrict__ U, double* __restrict__ q_stage,
+           double* __restrict__ eq, double* __restrict__ ineq, double* __restrict__ gradJ, double* __restrict__ jacF) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)C.N * B) return;
+    const int k = (int)(idx / B), i = (int)(idx % B);
+    const eepacc_vehicle& V = C.V;
+    auto Xk = [&](int kk, int c) { return X[((size_t)kk * 4 + c) * B + i]; };
+    auto Uk = [&](int kk, int c) { return U[((size_t)kk * 6 + c) * B + i]; };
+    const double s0 = Xk(k, 0), v0 = Xk(k, 1), th0 = Xk(k, 2), j0 = Xk(k, 3);
+    const double s1n = Xk(k + 1, 0), v1n = Xk(k + 1, 1), th1 = Xk(k + 1, 2), j1 = Xk(k + 1, 3);
+    const double Fm = Uk(k, 0), Fb = Uk(k, 1), xv = Uk(k, 2), xh = Uk(k, 3), xs = Uk(k, 4), xf = Uk(k, 5);
+    const double Fprev = k > 0 ? Uk(k - 1, 0) + Uk(k - 1, 1) : 0.0;                      // Uk_prev = 0 at k = 0 (:337)
+    const double F = Fm + Fb;
+    const double lm = V.lambda * V.m, mg = V.m * V.g;
+    const double kr = (30.0 / M_PI) * V.phi;
+
+    // ---- F = RK4 x 4 of (xdot, L), theta and j frozen over the interval (:262-278) ----
+    const double c0 = cos(th0), sn0 = sin(th0);
+    const double grav = V.c_r * mg * c0 + mg * sn0, dgrav = -V.c_r * mg * sn0 + mg * c0;   // and d/dtheta
+    const double ilm = 1.0 / lm;
+    double qF = 0.0;                                                  // d(cost integral)/dFm (direct dependence)
+    // one evaluation of (xdot, L) at speed vv: acceleration jet a, running cost jet l (weights w on the accumulators)
+    auto f = [&](const J3& vv, double w, J3& a, J3& qacc) {
+        const double k2 = -2.0 * V.zeta_a * vv.v;
+        a.v = ilm * (F - V.zeta_a * vv.v * vv.v - grav);
+        a.g[0] = ilm * (k2 * vv.g[0]);
+        a.g[1] = ilm * (k2 * vv.g[1] - dgrav);
+        a.g[2] = ilm * (1.0 + k2 * vv.g[2]);
+        double P, PF, Pr;
+        p_bat(C.b, Fm, kr * vv.v, P, PF, Pr);
+        const double dr = C.W[0] * Pr * kr, da = 2.0 * C.W[1] * a.v;
+        qacc.v = fma(w, C.W[0] * P + C.W[1] * a.v * a.v, qacc.v);
+        qacc.g[0] = fma(w, dr * vv.g[0] + da * a.g[0], qacc.g[0]);
+        qacc.g[1] = fma(w, dr * vv.g[1] + da * a.g[1], qacc.g[1]);
+        qacc.g[2] = fma(w, dr * vv.g[2] + da * a.g[2], qacc.g[2]);
+        qF = fma(w, C.W[0] * PF, qF);
+    };
+    const double DT = C.Ts / 4;
+    J3 v{v0, {1.0, 0.0, 0.0}}, ds{0.0, {0.0, 0.0, 0.0}}, q{0.0, {0.0, 0.0, 0.0}};
+    for (int m = 0; m < 4; ++m) {
+        J3 a, asum, vsum;
+        f(v, DT / 6, a, q);
+        asum = a; vsum = v;
+        const J3 v2 = axpy(DT / 2, a, v);
+        f(v2, DT / 3, a, q);
+        asum = axpy(2.0, a, asum); vsum = axpy(2.0, v2, vsum);
+        const J3 v3 = axpy(DT / 2, a, v);
+        f(v3, DT / 3, a, q);
+        asum = axpy(2.0, a, asum); vsum = axpy(2.0, v3, vsum);
+        const J3 v4 = axpy(DT, a, v);
+        f(v4, DT / 6, a, q);
+        asum = axpy(1.0, a, asum); vsum = axpy(1.0, v4, vsum);
+        ds = axpy(DT / 6, vsum, ds);
+        v = axpy(DT / 6, asum, v);
+    }
+    const double* W = C.W;
+    q_stage[idx] = q.v + C.Ts * (W[2] * j0 * j0 + W[3] * xv + W[4] * (xh * xh + 1e2 * xh) + W[5] * xs + W[6] * xf);   // L of :240
+    if (gradJ) {
+        double* g = gradJ + (size_t)k * 10 * B + i;
+        g[0 * (size_t)B] = 0.0;
+        g[1 * (size_t)B] = q.g[0];
+        g[2 * (size_t)B] = q.g[1];
+        g[3 * (size_t)B] = C.Ts * 2.0 * W[2] * j0;
+        g[4 * (size_t)B] = qF + q.g[2];
+        g[5 * (size_t)B] = q.g[2];
+        g[6 * (size_t)B] = C.Ts * W[3];
+        g[7 * (size_t)B] = C.Ts * W[4] * (2.0 * xh + 1e2);
+        g[8 * (size_t)B] = C.Ts * W[5];
+        g[9 * (size_t)B] = C.Ts * W[6];
+    }
+    if (jacF) {
+        double* jf = jacF + (size_t)k * 6 * B + i;
+        jf[0 * (size_t)B] = ds.g[0]; jf[1 * (size_t)B] = ds.g[1]; jf[2 * (size_t)B] = ds.g[2];
+        jf[3 * (size_t)B] = v.g[0];  jf[4 * (size_t)B] = v.g[1];  jf[5 * (size_t)B] = v.g[2];
+    }
+
+    // ---- equality rows (:357-376) ----
+    const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
+    double val, sl;
+    double* e = eq + (size_t)k * 4 * B + i;
+    e[0] = s0 + ds.v - s1n;
+    e[(size_t)B] = v.v - v1n;
+    if (C.flat) val = 0.0; else pwa(t_slope, s1n, val, sl);
+    e[2 * (size_t)B] = th1 - val;
+    const double c1 = cos(th1), sn1 = sin(th1);
+    const double drag1 = V.zeta_a * v1n * v1n + V.c_r * mg * c1 + mg * sn1;
+    const double drag0 = V.zeta_a * v0 * v0 + V.c_r * mg * c0 + mg * sn0;
+    e[3 * (size_t)B] = j1 - (F - drag1 - Fprev + drag0) / (lm * C.Ts);
+
+    // ---- inequality rows (:378-501), orientation value <= 0, then the bounds ----
+    double* r = ineq + (size_t)k * C.R * B + i;
+    int n = 0;
+    auto put = [&](double x) { r[(size_t)n * B] = x; ++n; };
+    const double a = (F - drag1) / lm;
+    put(-(Fm * v1n + V.P_m_max / V.eta_TF + xf));
+    put(Fm * v1n - V.P_m_max * V.eta_TF - xf);
+    put(-(F + V.mu * mg * c1 + xf));
+    put(F - V.mu * mg * c1 - xf);
+    const double rear = V.h_g * V.lambda * a + V.h_g * V.zeta_a / V.m * v1n * v1n + V.g * (V.L_f * c1 + V.h_g * sn1);
+    const double kF = V.L / (V.mu * V.m);
+    put(-(kF * Fm + rear + xf));
+    put(kF * Fm - rear - xf);
+    const double iso_v[4] = {0.0, 5.0, 20.0, 25.0};                                        // :79-84
+    const double iso_amin[4] = {-4.0, -4.0, -2.0, -2.0}, iso_amax[4] = {5.0, 5.0, 3.5, 3.5}, iso_j[4] = {5.0, 5.0, 2.5, 2.5};
+    pwa(Tab{iso_v, iso_amin, 4}, v1n, val, sl);
+    put(-(a - val + xf));
+    pwa(Tab{iso_v, iso_amax, 4}, v1n, val, sl);
+    put(a - val - xf);
+    pwa(Tab{iso_v, iso_j, 4}, v1n, val, sl);
+    put(-(j1 + val + xf));
+    put(j1 - val - xf);
+    pwa(Tab{blob + C.o_vlim, blob + C.o_vlim + C.n_vlim, C.n_vlim}, s1n, val, sl);
+    put(v1n - val - xf);
+    pwa(Tab{blob + C.o_curv, blob + C.o_curv + C.n_curv, C.n_curv}, s1n, val, sl);
+    put(v1n - C.alpha * pow(fabs(val), -1.0 / 3.0) - xf);
+    pwa(Tab{blob + C.o_stop, blob + C.o_stop + C.n_stop, C.n_stop}, s1n, val, sl);
+    put(v1n - val - xs);
+    for (int t = 0; t < C.n_tl; ++t) {
+        pwa(Tab{blob + C.o_tls + 3 * t, C.tl_v, 3}, s1n, val, sl);
+        const double tt = blob[C.o_tlstate + (size_t)t * C.N + k];
+        put(v1n - val - tt - xs);
+        put(-(v1n + val + 1e3 - 10.0 - tt + xs));
+    }
+    pwa(Tab{blob + C.o_vinc, blob + C.o_vinc + C.n_vinc, C.n_vinc}, s1n, val, sl);
+    put(-(v1n - val + xv));
+    const double stv = s_tv[(size_t)k * B + i];
+    put(s1n - (stv - C.h_min));
+    put(s1n + C.tau_min * v1n - xs - stv);
+    const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;             // :494-496
+    put(s1n + v1n * T_hwp + v1n * v1n * G_hwp - xh - (stv - A_hwp));
+    put(C.Fm_min - Fm);
+    put(Fm - C.Fm_max);
+    put(Fb);
+    put(-xv); put(-xh); put(-xs); put(-xf);
+    put(-s1n);
+    put(-v1n);
+    put(v1n - V.v_max);
+    if (C.has_goal) put(s1n - C.s_goal);
+}
+
+// objective per route: 64 routes x 16 interval slices per workgroup (loads stay unit-stride across the routes), each
+// slice sums its intervals k = slice, slice + 16, ... in order, the 16 partial sums are added in slice order: a fixed
+// summation tree, bit-reproducible
+constexpr int SUM_SLICES = 16;
+__global__ void __launch_bounds__(64 * SUM_SLICES)
+k_nlp_sum(int N, int B, const double* __restrict__ q_stage, double* __restrict__ J) {
+    __shared__ double part[SUM_SLICES][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (i < B)
+        for (int k = slice; k < N; k += SUM_SLICES) acc += q_stage[(size_t)k * B + i];
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && i < B) {
+        double t = part[0][lane];
+        for (int q = 1; q < SUM_SLICES; ++q) t += part[q][lane];
+        J[i] = t;
+    }
+}
+
+}  // namespace
+
+struct eepacc_nlp_handle {
+    int device = 0;
+    NlpDev C;
+    double* d_blob = nullptr;
+    double* d_q = nullptr;
+    size_t q_cap = 0;
+};
+
+#define NLPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return eepacc::set_error(EEPACC_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" int eepacc_nlp_sizeof_problem(void) { return (int)sizeof(eepacc_nlp_problem); }
+
+extern "C" int eepacc_nlp_rows(const eepacc_nlp_problem* p) {
+    if (!p) return EEPACC_EINVAL;
+    return 17 + 2 * p->n_tl + 10 + (std::isfinite(p->s_goal) ? 1 : 0);
+}
+
+extern "C" int eepacc_nlp_create(eepacc_nlp_handle** out, const eepacc_nlp_problem* p, const eepacc_vehicle* V, int device) {
+    if (!out || !p || !V) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_create: null argument");
+    *out = nullptr;
+    if (p->N < 1 || !(p->Ts > 0)) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_create: N >= 1 and Ts > 0 required");
+    if (p->n_tl < 0 || p->n_tl > EEPACC_NLP_MAX_TL) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_create: at most 8 traffic lights");
+    struct T { int n; const double* x; const double* y; const char* name; };
+    const T tabs[5] = {{p->n_vlim, p->s_vlim, p->v_vlim, "speed limit"}, {p->n_curv, p->s_curv, p->curvature, "curvature"},
+                       {p->n_slope, p->s_slope, p->slope, "slope"}, {p->n_stop, p->s_stop, p->v_stop, "stop"},
+                       {p->n_vinc, p->s_vinc, p->v_vinc, "velocity incentive"}};
+    for (const T& t : tabs) {
+        if (t.n < 2 || t.n > EEPACC_NLP_MAX_KNOTS || !t.x || !t.y)
+            return eepacc::set_error(EEPACC_EINVAL, std::string("eepacc_nlp_create: ") + t.name + " table needs 2..64 knots");
+        for (int i = 1; i < t.n; ++i)
+            if (!(t.x[i] >= t.x[i - 1])) return eepacc::set_error(EEPACC_EINVAL, std::string("eepacc_nlp_create: ") + t.name + " knots must ascend");
+    }
+    if (p->n_tl > 0 && (!p->tl_s || !p->tl_state)) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_create: traffic-light tables missing");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return eepacc::set_error(EEPACC_EDEVICE, "eepacc_nlp_create: no HIP device (libeepacc has no CPU path)");
+    if (device < 0 || device >= ndev) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_create: bad device index");
+    NLPCHK(hipSetDevice(device));
+    eepacc_nlp_handle* h = new (std::nothrow) eepacc_nlp_handle();
+    if (!h) return eepacc::set_error(EEPACC_ENOMEM, "eepacc_nlp_create: out of host memory");
+    h->device = device;
+    NlpDev& C = h->C;
+    std::memset(&C, 0, sizeof(C));
+    C.N = p->N; C.n_tl = p->n_tl; C.flat = p->flat ? 1 : 0; C.Ts = p->Ts;
+    std::memcpy(C.W, p->W, sizeof(C.W));
+    std::memcpy(C.b, p->b, sizeof(C.b));
+    C.s_goal = p->s_goal; C.h_min = p->h_min; C.tau_min = p->tau_min; C.alpha = p->alpha_TTL;
+    C.has_goal = std::isfinite(p->s_goal) ? 1 : 0;
+    C.R = eepacc_nlp_rows(p);
+    C.V = *V;
+    C.Fm_min = -V->phi * V->T_m_max / V->eta_TF;                                           // RunOpt_NLP.m:194-195
+    C.Fm_max = V->phi * V->T_m_max * V->eta_TF;
+    std::memcpy(C.tl_v, p->tl_v, sizeof(C.tl_v));
+    std::vector<double> blob;
+    auto push = [&](const T& t) { int o = (int)blob.size(); blob.insert(blob.end(), t.x, t.x + t.n); blob.insert(blob.end(), t.y, t.y + t.n); return o; };
+    C.n_vlim = p->n_vlim; C.o_vlim = push(tabs[0]);
+    C.n_curv = p->n_curv; C.o_curv = push(tabs[1]);
+    C.n_slope = p->n_slope; C.o_slope = push(tabs[2]);
+    C.n_stop = p->n_stop; C.o_stop = push(tabs[3]);
+    C.n_vinc = p->n_vinc; C.o_vinc = push(tabs[4]);
+    C.o_tls = (int)blob.size();
+    if (p->n_tl) blob.insert(blob.end(), p->tl_s, p->tl_s + 3 * (size_t)p->n_tl);
+    C.o_tlstate = (int)blob.size();
+    if (p->n_tl) blob.insert(blob.end(), p->tl_state, p->tl_state + (size_t)p->n_tl * p->N);
+    hipError_t e = hipMalloc(&h->d_blob, blob.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        eepacc_nlp_destroy(h);
+        return eepacc::set_error(EEPACC_EDEVICE, std::string("eepacc_nlp_create: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return EEPACC_OK;
+}
+
+extern "C" void eepacc_nlp_destroy(eepacc_nlp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_q) (void)hipFree(h->d_q);
+    delete h;
+}
+
+extern "C" int eepacc_nlp_eval(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const double* X_dev, const double* U_dev,
+                               double* J_dev, double* eq_dev, double* ineq_dev, double* gradJ_dev, double* jacF_dev,
+                               void* stream) {
+    if (!h || B < 1 || !s_tv_dev || !X_dev || !U_dev || !J_dev || !eq_dev || !ineq_dev)
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_eval: null argument or B < 1");
+    NLPCHK(hipSetDevice(h->device));
+    const size_t units = (size_t)h->C.N * B;
+    if (units > h->q_cap) {
+        if (h->d_q) (void)hipFree(h->d_q);
+        h->d_q = nullptr; h->q_cap = 0;
+        NLPCHK(hipMalloc(&h->d_q, units * sizeof(double)));
+        h->q_cap = units;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((units + threads - 1) / threads);
+    hipLaunchKernelGGL(k_nlp_eval, dim3(blocks), dim3(threads), 0, st, h->C, h->d_blob, B, s_tv_dev, X_dev, U_dev, h->d_q,
+                       eq_dev, ineq_dev, gradJ_dev, jacF_dev);
+    NLPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_nlp_sum, dim3((B + 63) / 64), dim3(64 * SUM_SLICES), 0, st, h->C.N, B, h->d_q, J_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream) {
+    if (!h) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_synchronize: null handle");
+    NLPCHK(hipSetDevice(h->device));
+    NLPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return EEPACC_OK;
+}

@@ -29,6 +29,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        import torch  # noqa: F401  -- before the CDLL: libeepacc must bind to the HIP runtime torch ships, not load a second one
+    except ImportError:
+        pass
     if not os.path.exists(_LIBPATH):
         raise EepaccError(f"{_LIBPATH} not found: build it with `python -m eepacc_mpc_casadi_matlab_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -1,0 +1,323 @@
+"""Host side of RunOpt_NLP (ABO/RunOpt_NLP.m).
+
+* ``build_tables`` -- the lookup tables RunOpt_NLP.m:63-184 builds before it formulates the problem (stops,
+  traffic lights, the velocity-incentive profile through minPWA / SaturateSlopePWA / SimplifyPWA), as plain arrays.
+* ``NlpEvaluator`` -- front-end of include/eepacc_nlp.h: objective, constraint rows, objective gradient and the
+  integrator's Jacobian blocks of the multiple-shooting NLP for a batch of routes on the GPU (what IPOPT calls back
+  into every iteration, RunOpt_NLP.m:505-510).  There is no CPU path: without the HIP library or a GPU it raises.
+* ``postprocess`` -- RunOpt_NLP.m:545-605 (derived quantities and the cost series of optSol).
+
+The interior-point iteration itself is not in the library yet.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Any, Dict
+
+import numpy as np
+
+from ._abi import Vehicle, make_vehicle
+
+__all__ = ["pwa", "build_tables", "NlpEvaluator", "nlp_rows", "postprocess"]
+
+
+def pwa(x, xs, ys):
+    """Linear interpolation with linear extrapolation; returns (value, slope of the segment used)."""
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    i = np.clip(np.searchsorted(xs, x, side="right") - 1, 0, len(xs) - 2)
+    dx = xs[i + 1] - xs[i]
+    sl = np.where(dx > 0, (ys[i + 1] - ys[i]) / np.where(dx > 0, dx, 1.0), 0.0)
+    return ys[i] + sl * (x - xs[i]), sl
+
+
+def _interp_pwa(d, doms, vals):
+    return float(np.interp(d, doms, vals))
+
+
+def min_pwa(Ad, Av, Bd, Bv, simplify):
+    """Functions/PWA_function_manipulation/minPWA.m: pointwise minimum of two PWA functions."""
+    Ad, Av, Bd, Bv = (list(map(float, a)) for a in (Ad, Av, Bd, Bv))
+    if Ad[0] != Bd[0]:
+        if Ad[0] > Bd[0]:
+            Ad, Av = [Bd[0]] + Ad, [Av[0]] + Av
+        else:
+            Bd, Bv = [Ad[0]] + Bd, [Bv[0]] + Bv
+    if Ad[-1] != Bd[-1]:
+        if Ad[-1] > Bd[-1]:
+            Bd, Bv = Bd + [Ad[-1]], Bv + [Bv[-1]]
+        else:
+            Ad, Av = Ad + [Bd[-1]], Av + [Av[-1]]
+    Ad, Av = (list(a) for a in simplify(np.array(Ad), np.array(Av)))
+    Bd, Bv = (list(a) for a in simplify(np.array(Bd), np.array(Bv)))
+    Ad, Av = Ad + [Ad[-1] + 1, Ad[-1] + 2], Av + [Av[-1], Av[-1]]
+    Bd, Bv = Bd + [Bd[-1] + 1, Bd[-1] + 2], Bv + [Bv[-1], Bv[-1]]
+    Cd, Cv = [], []
+    iA = iB = 0
+    doneA = doneB = False
+    while True:
+        Ad1, Av1, Ad2, Av2 = Ad[iA], Av[iA], Ad[iA + 1], Av[iA + 1]
+        Bd1, Bv1, Bd2, Bv2 = Bd[iB], Bv[iB], Bd[iB + 1], Bv[iB + 1]
+        As = (Av2 - Av1) / (Ad2 - Ad1)
+        Bs = (Bv2 - Bv1) / (Bd2 - Bd1)
+        if (Av1 > Bv1 and Av2 < Bv2) or (Av1 < Bv1 and Av2 > Bv2):
+            s1 = (Bv1 - Av1 + (Ad1 - Bd1) * Bs) / (As - Bs)
+            Id = Ad1 + s1
+            if Ad1 <= Id <= Ad2 and Bd1 <= Id <= Bd2:
+                Cd.append(Id)
+                Cv.append(Av1 + As * s1)
+        if Ad2 < Bd2:
+            if Av1 <= _interp_pwa(Ad1, Bd, Bv):
+                Cd.append(Ad1)
+                Cv.append(Av1)
+            iA += 1
+            if iA == len(Ad) - 2:
+                doneA = True
+        else:
+            if Bv1 <= _interp_pwa(Bd1, Ad, Av):
+                Cd.append(Bd1)
+                Cv.append(Bv1)
+            iB += 1
+            if iB == len(Bd) - 2:
+                doneB = True
+        if doneA and doneB:
+            break
+    order = np.argsort(np.array(Cd), kind="stable")
+    return np.array(Cd)[order], np.array(Cv)[order]
+
+
+def saturate_slope_pwa(doms, vals, c_des):
+    """SaturateSlopePWA.m (+ FixCrossingPWA.m between its two passes)."""
+    doms = np.array(doms, dtype=np.float64)
+    vals = np.array(vals, dtype=np.float64)
+
+    def one_pass():
+        for i in range(1, len(doms)):
+            c = (vals[i] - vals[i - 1]) / (doms[i] - doms[i - 1])
+            if c > 0 and c > c_des:
+                doms[i] = doms[i - 1] + (vals[i] - vals[i - 1]) / c_des
+            elif c < 0 and c < -c_des:
+                doms[i - 1] = doms[i] + (vals[i] - vals[i - 1]) / c_des
+    one_pass()
+    d0 = doms.copy()
+    for cc in np.nonzero(np.diff(d0) <= 0)[0]:               # FixCrossingPWA.m (0-based cc = curCross-1)
+        Ad1, Av1, Ad2, Av2 = doms[cc - 1], vals[cc - 1], doms[cc], vals[cc]
+        Bd1, Bv1, Bd2, Bv2 = doms[cc + 1], vals[cc + 1], doms[cc + 2], vals[cc + 2]
+        As = (Av2 - Av1) / (Ad2 - Ad1)
+        Bs = (Bv2 - Bv1) / (Bd2 - Bd1)
+        s1 = (Bv1 - Av1 + (Ad1 - Bd1) * Bs) / (As - Bs)
+        Iv = Av1 + As * s1
+        doms[cc], vals[cc] = d0[cc + 1], Iv
+        doms[cc + 1], vals[cc + 1] = d0[cc], Iv
+    one_pass()
+    return doms, vals
+
+
+def build_tables(OPT: Dict[str, Any]) -> Dict[str, Any]:
+    """Lookup tables of RunOpt_NLP.m:63-184 as plain arrays."""
+    from .settings import SimplifyPWA
+    T: Dict[str, Any] = {}
+    Ts = float(OPT["Ts"])
+    N = int(round(float(OPT["t_sim"]) / Ts))
+    T["slope"] = (np.asarray(OPT["s_slope"], float), np.asarray(OPT["slope"], float))
+    T["flat"] = bool(np.sum(OPT["slope"]) < 1e-1)                                          # :363
+    T["vlim"] = (np.asarray(OPT["s_speedLim"], float), np.asarray(OPT["v_speedLim"], float))
+    T["curv"] = (np.asarray(OPT["s_curv"], float), np.asarray(OPT["curvature"], float))
+    incr = float(OPT["stopRefDist"]) * float(OPT["stopRefVelSlope"])
+    sS, vS = [], []
+    for loc in np.sort(np.asarray(OPT["stopLoc"], float).ravel()):                         # :95-98
+        sS += [loc - OPT["stopRefDist"], loc, loc + OPT["stopRefDist"]]
+        vS += [incr, float(OPT["stopVel"]), incr]
+    for i in range(len(vS) - 1):                                                           # :101-109
+        if sS[i + 1] <= sS[i]:
+            corr = .5 * (sS[i] - sS[i + 1]) + sS[i + 1]
+            val = incr / (1 + OPT["stopRefDist"] / (sS[i] - sS[i + 1]))
+            vS[i] = vS[i + 1] = val
+            sS[i], sS[i + 1] = corr - 1, corr + 1
+    if len(sS) < 1:
+        sS, vS = [0.0, 1.0], [1e5, 1e5]                                                     # :112-115
+    T["stop"] = (np.array(sS, float), np.array(vS, float))
+    TL = np.asarray(OPT["TLLoc"], float).reshape(-1, 4) if np.size(OPT["TLLoc"]) else np.zeros((0, 4))
+    T["tl_s"] = np.zeros((len(TL), 3))
+    T["tl_v"] = np.array([incr, float(OPT["TLstopVel"]), incr])
+    T["tl_state"] = np.zeros((len(TL), N))
+    for i, row in enumerate(TL):                                                           # :128-156
+        T["tl_s"][i] = [row[0] - OPT["stopRefDist"], row[0], row[0] + OPT["stopRefDist"]]
+        for k in range(N):
+            red = math.fmod(k * Ts - row[1], row[2] + row[3])
+            if red < 0:
+                red += row[2] + row[3]                                                     # MATLAB mod
+            T["tl_state"][i, k] = .2 if red < row[2] else 1e3
+    with np.errstate(divide="ignore"):
+        vc = float(OPT["alpha_TTL"]) * np.abs(T["curv"][1]) ** (-1.0 / 3.0)
+    sI, vI = min_pwa(T["vlim"][0], T["vlim"][1], T["curv"][0], vc, SimplifyPWA)           # :162
+    sI, vI = saturate_slope_pwa(sI, vI, 0.5)                                               # :165
+    keep = np.diff(sI) != 0                            # :168-172 ("~diff(s)==0" parses as (~diff(s))==0; short mask)
+    sI, vI = np.append(sI[:-1][keep], sI[-1]), np.append(vI[:-1][keep], vI[-1])
+    sI, vI = SimplifyPWA(sI, vI)                                                           # :175
+    T["vinc"] = (np.asarray(sI, float), np.asarray(vI, float))
+    T["N"] = N
+    return T
+
+
+
+
+# ----------------------------------------------------------------------------------------------
+# front-end of include/eepacc_nlp.h
+# ----------------------------------------------------------------------------------------------
+class NlpProblemPOD(C.Structure):
+    _fields_ = [("N", C.c_int32), ("n_tl", C.c_int32), ("flat", C.c_int32), ("pad", C.c_int32),
+                ("Ts", C.c_double), ("W", C.c_double * 7), ("b", C.c_double * 21),
+                ("s_goal", C.c_double), ("h_min", C.c_double), ("tau_min", C.c_double), ("alpha_TTL", C.c_double),
+                ("n_vlim", C.c_int32), ("n_curv", C.c_int32), ("n_slope", C.c_int32), ("n_stop", C.c_int32),
+                ("n_vinc", C.c_int32), ("pad2", C.c_int32),
+                ("s_vlim", C.POINTER(C.c_double)), ("v_vlim", C.POINTER(C.c_double)),
+                ("s_curv", C.POINTER(C.c_double)), ("curvature", C.POINTER(C.c_double)),
+                ("s_slope", C.POINTER(C.c_double)), ("slope", C.POINTER(C.c_double)),
+                ("s_stop", C.POINTER(C.c_double)), ("v_stop", C.POINTER(C.c_double)),
+                ("s_vinc", C.POINTER(C.c_double)), ("v_vinc", C.POINTER(C.c_double)),
+                ("tl_s", C.POINTER(C.c_double)), ("tl_v", C.c_double * 3), ("tl_state", C.POINTER(C.c_double))]
+
+
+def nlp_rows(n_tl: int, s_goal: float) -> int:
+    """Rows per interval (include/eepacc_nlp.h: eepacc_nlp_rows)."""
+    return 17 + 2 * n_tl + 10 + (1 if math.isfinite(s_goal) else 0)
+
+
+def _bind(lib):
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    lib.eepacc_nlp_rows.argtypes = [C.POINTER(NlpProblemPOD)]
+    lib.eepacc_nlp_create.argtypes = [C.POINTER(vp), C.POINTER(NlpProblemPOD), C.POINTER(Vehicle), C.c_int]
+    lib.eepacc_nlp_destroy.argtypes = [vp]
+    lib.eepacc_nlp_destroy.restype = None
+    lib.eepacc_nlp_eval.argtypes = [vp, C.c_int] + [vp] * 9
+    lib.eepacc_nlp_synchronize.argtypes = [vp, vp]
+    return lib
+
+
+class NlpEvaluator:
+    """Batched nlp_f / nlp_g / nlp_grad_f / integrator Jacobian of RunOpt_NLP's problem on one GPU.
+
+    ``OPTsettings`` as for RunOpt_NLP (t_sim, Ts, W_NLP, b_fifthOrder / b_quadr, useFifthOrderFit_NLP, the route
+    tables of GenerateUseCase, h_min, tau_min, alpha_TTL, s_goal); ``V`` from SetVehicleParameters."""
+
+    def __init__(self, OPTsettings: Dict[str, Any], V: Dict[str, float], device: int = 0):
+        from .engine import load_library, EepaccError
+        import torch
+        self._err = EepaccError
+        self.lib = _bind(load_library())
+        if not torch.cuda.is_available():
+            # still go through the library so that the failure is the library's own (no CPU path behind this class)
+            pass
+        T = build_tables(OPTsettings)
+        self.tables = T
+        self.N = int(T["N"])
+        self.n_tl = int(T["tl_s"].shape[0])
+        p = NlpProblemPOD()
+        p.N, p.n_tl, p.flat = self.N, self.n_tl, int(T["flat"])
+        p.Ts = float(OPTsettings["Ts"])
+        p.W[:] = [float(x) for x in np.asarray(OPTsettings["W_NLP"], float)]
+        if OPTsettings.get("useFifthOrderFit_NLP", True):
+            b = np.asarray(OPTsettings["b_fifthOrder"], float)
+        else:
+            b = np.concatenate([np.asarray(OPTsettings["b_quadr"], float), np.zeros(15)])
+        p.b[:] = [float(x) for x in b]
+        p.s_goal, p.h_min = float(OPTsettings["s_goal"]), float(OPTsettings["h_min"])
+        p.tau_min, p.alpha_TTL = float(OPTsettings["tau_min"]), float(OPTsettings["alpha_TTL"])
+        self._keep = []
+
+        def tab(key):
+            xs = np.ascontiguousarray(T[key][0], dtype=np.float64)
+            ys = np.ascontiguousarray(T[key][1], dtype=np.float64)
+            self._keep += [xs, ys]
+            return len(xs), xs.ctypes.data_as(C.POINTER(C.c_double)), ys.ctypes.data_as(C.POINTER(C.c_double))
+        p.n_vlim, p.s_vlim, p.v_vlim = tab("vlim")
+        p.n_curv, p.s_curv, p.curvature = tab("curv")
+        p.n_slope, p.s_slope, p.slope = tab("slope")
+        p.n_stop, p.s_stop, p.v_stop = tab("stop")
+        p.n_vinc, p.s_vinc, p.v_vinc = tab("vinc")
+        tls = np.ascontiguousarray(T["tl_s"], dtype=np.float64)
+        tst = np.ascontiguousarray(T["tl_state"], dtype=np.float64)
+        self._keep += [tls, tst]
+        if self.n_tl:
+            p.tl_s = tls.ctypes.data_as(C.POINTER(C.c_double))
+            p.tl_state = tst.ctypes.data_as(C.POINTER(C.c_double))
+        p.tl_v[:] = [float(x) for x in T["tl_v"]]
+        self.pod = p
+        self.R = int(self.lib.eepacc_nlp_rows(C.byref(p)))
+        assert self.R == nlp_rows(self.n_tl, p.s_goal)
+        self.V = make_vehicle(V)
+        self.h = C.c_void_p()
+        rc = self.lib.eepacc_nlp_create(C.byref(self.h), C.byref(p), C.byref(self.V), device)
+        if rc != 0:
+            raise EepaccError("eepacc_nlp_create failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            self.lib.eepacc_nlp_destroy(h)
+            self.h = None
+
+    def eval(self, s_tv, X, U, want_grad: bool = True, out=None):
+        """s_tv [N][B], X [N+1][4][B], U [N][6][B] (torch CUDA tensors or numpy arrays, fp64).
+        Returns dict(J [B], eq [N][4][B], ineq [N][R][B], gradJ [N][10][B], jacF [N][2][3][B]) of CUDA tensors."""
+        import torch
+        dev = torch.device("cuda", self.device)
+
+        def d(x):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+            return t.to(device=dev, dtype=torch.float64).contiguous()
+        s_tv, X, U = d(s_tv), d(X), d(U)
+        N = self.N
+        B = int(X.shape[-1])
+        assert X.shape == (N + 1, 4, B) and U.shape == (N, 6, B) and s_tv.shape == (N, B)
+        o = out or {}
+        if "J" not in o:
+            o["J"] = torch.empty(B, dtype=torch.float64, device=dev)
+            o["eq"] = torch.empty((N, 4, B), dtype=torch.float64, device=dev)
+            o["ineq"] = torch.empty((N, self.R, B), dtype=torch.float64, device=dev)
+            if want_grad:
+                o["gradJ"] = torch.empty((N, 10, B), dtype=torch.float64, device=dev)
+                o["jacF"] = torch.empty((N, 2, 3, B), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        g = o["gradJ"].data_ptr() if want_grad else None
+        jf = o["jacF"].data_ptr() if want_grad else None
+        rc = self.lib.eepacc_nlp_eval(self.h, B, s_tv.data_ptr(), X.data_ptr(), U.data_ptr(), o["J"].data_ptr(),
+                                      o["eq"].data_ptr(), o["ineq"].data_ptr(), g, jf, stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_eval failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return o
+
+    def synchronize(self):
+        import torch
+        stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+        rc = self.lib.eepacc_nlp_synchronize(self.h, stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_synchronize failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+
+
+def postprocess(OPTsettings: Dict[str, Any], V: Dict[str, float], v_opt, Fm_opt, j_opt=None, slacks=None):
+    """RunOpt_NLP.m:545-605: rpm, P (fifth-order surface), E, a, Tm and, given j_opt [N+1] and the slacks
+    [N][4] = (xi_v, xi_h, xi_s, xi_f), the running cost series cost_P ... cost_xi_f of optSol."""
+    Ts = float(OPTsettings["Ts"])
+    v_opt, Fm_opt = np.asarray(v_opt, float), np.asarray(Fm_opt, float)
+    rpm = (30 / math.pi) * v_opt[:-1] * V["phi"]
+    b = np.asarray(OPTsettings["b_fifthOrder"], float)
+    F, r = Fm_opt, rpm
+    P = (b[0] + b[1] * F + b[2] * r + b[3] * F**2 + b[4] * F * r + b[5] * r**2 + b[6] * F**3 + b[7] * F**2 * r
+         + b[8] * F * r**2 + b[9] * r**3 + b[10] * F**4 + b[11] * F**3 * r + b[12] * F**2 * r**2 + b[13] * F * r**3
+         + b[14] * r**4 + b[15] * F**5 + b[16] * F**4 * r + b[17] * F**3 * r**2 + b[18] * F**2 * r**3
+         + b[19] * F * r**4 + b[20] * r**5)                                     # GetMotorPower_FifthOrderSurface
+    out = dict(rpm_opt=rpm, P_opt=P, E_opt=Ts * np.cumsum(P), a_opt=np.diff(v_opt) / Ts,
+               Tm_opt=Fm_opt / V["phi"] / (V["eta_TF"] ** np.sign(Fm_opt)))
+    if j_opt is not None and slacks is not None:
+        W = np.asarray(OPTsettings["W_NLP"], float)
+        sl = np.asarray(slacks, float)
+        out.update(cost_P=W[0] * np.cumsum(P), cost_a=W[1] * np.cumsum(out["a_opt"] ** 2),
+                   cost_j=W[2] * np.cumsum(np.asarray(j_opt, float)[:len(P)] ** 2),
+                   cost_xi_v=W[3] * np.cumsum(sl[:, 0]), cost_xi_h=W[4] * np.cumsum(sl[:, 1]),
+                   cost_xi_s=W[5] * np.cumsum(sl[:, 2]), cost_xi_f=W[6] * np.cumsum(sl[:, 3]))
+    return out

@@ -1,0 +1,90 @@
+/*
+ * eepacc_nlp.h -- C ABI of the batched function evaluator of the full-route problem of RunOpt_NLP.
+ *
+ * ABO/RunOpt_NLP.m (ORIG/RunOpt_NLP.m is the same file) builds one nonlinear program per route
+ * (multiple shooting, :296-501: per interval k the controls U_k = [Fm,Fb,xi_v,xi_h,xi_s,xi_f] and the
+ * node X_{k+1} = [s,v,theta,j]) and hands it to IPOPT (:505-510).  What IPOPT calls back into, once per
+ * iteration, are CasADi's generated functions nlp_f, nlp_g, nlp_grad_f and nlp_jac_g; everything in them is
+ * stage-local, so for a batch of routes it is one thread per (route, interval).  eepacc_nlp_eval is that
+ * evaluation for B routes at once: the objective, every constraint row, the objective gradient and the
+ * Jacobian blocks of the RK4 x 4 integrator (the only rows whose derivatives are not closed-form).
+ *
+ * SURVEY.md section 8f rank 2 asks for the whole of RunOpt_NLP as a batched solver on the GPU.  This
+ * header is the evaluation half of it; the interior-point iteration on top (stage-wise Riccati
+ * factorisation, oracle/nlp_oracle.py: solve) runs on the CPU as a model only and is not part of the
+ * library yet.
+ *
+ * Layout: batch-major structure-of-arrays like eepacc.h -- item (k, c) of route i is x[(k*C + c)*B + i].
+ * All pointers named *_dev are device allocations on the current device; tables in eepacc_nlp_problem are
+ * host pointers that eepacc_nlp_create copies.
+ */
+#ifndef EEPACC_NLP_H
+#define EEPACC_NLP_H
+
+#include <stdint.h>
+#include "eepacc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EEPACC_NLP_MAX_KNOTS 64    /* per lookup table */
+#define EEPACC_NLP_MAX_TL     8    /* traffic lights   */
+#define EEPACC_NLP_NX         4    /* s, v, theta, j            (RunOpt_NLP.m:204-209) */
+#define EEPACC_NLP_NU         6    /* Fm, Fb, xi_v, xi_h, xi_s, xi_f  (:212-222)       */
+
+/* One route family: everything RunOpt_NLP.m:17-184 unpacks or precomputes on the host.  Lookup tables are the
+ * knots / values handed to casadi.interpolant('LUT','linear',...) (linear interpolation, linear extrapolation
+ * from the end segments). */
+typedef struct eepacc_nlp_problem {
+    int32_t N;                       /* t_sim / Ts (:189)                                             */
+    int32_t n_tl;                    /* traffic lights (:120-157); 0 = none                           */
+    int32_t flat;                    /* sum(slope) < 1e-1: theta rows are  theta_{k+1} = 0 (:363-364)  */
+    int32_t pad;
+    double  Ts;
+    double  W[7];                    /* W_NLP = [w_P,w_a,w_j,w_v,w_h,w_s,w_f] (:53-61)                 */
+    double  b[21];                   /* power fit of the objective: b_fifthOrder, or b_quadr followed by 15 zeros
+                                        (useFifthOrderFit_NLP, :226-236)                              */
+    double  s_goal, h_min, tau_min, alpha_TTL;
+    int32_t n_vlim, n_curv, n_slope, n_stop, n_vinc, pad2;
+    const double *s_vlim, *v_vlim;   /* speedLimLookup (:69)                                          */
+    const double *s_curv, *curvature;/* curvatureLookup (:73)                                         */
+    const double *s_slope, *slope;   /* slopeLookup (:65)                                             */
+    const double *s_stop, *v_stop;   /* stopMaxVelLookup (:88-117)                                    */
+    const double *s_vinc, *v_vinc;   /* velIncentiveLookup (:160-184)                                 */
+    const double *tl_s;              /* [n_tl][3] knots of tlMaxVelLookup{i} (:141-142)               */
+    double        tl_v[3];           /* its values [stopRefvelIncr, TLstopVel, stopRefvelIncr]        */
+    const double *tl_state;          /* [n_tl][N] tlSPATLookup{i}(k*Ts): 0.2 red / 1e3 green (:144-154)*/
+} eepacc_nlp_problem;
+
+typedef struct eepacc_nlp_handle eepacc_nlp_handle;
+
+/* Rows per interval in `ineq` (orientation: value <= 0), in the order of RunOpt_NLP.m:378-501 followed by the
+ * variable bounds of :330-333,352-355:  17 + 2*n_tl + 10 (+1 when s_goal is finite). */
+int eepacc_nlp_rows(const eepacc_nlp_problem* p);
+int eepacc_nlp_sizeof_problem(void);   /* sizeof(eepacc_nlp_problem) as compiled: binding self-check */
+
+/* Replaces the problem construction of RunOpt_NLP.m:186-503 (tables to the device). */
+int  eepacc_nlp_create(eepacc_nlp_handle** out, const eepacc_nlp_problem* p, const eepacc_vehicle* V, int device);
+void eepacc_nlp_destroy(eepacc_nlp_handle* h);
+
+/* nlp_f / nlp_g / nlp_grad_f / the integrator blocks of nlp_jac_g for B routes (RunOpt_NLP.m:505-510: what
+ * `solver(...)` evaluates every iteration).
+ *   s_tv_dev [N][B]          lead-vehicle position, sample k is the one interval k reads (s_tv(k+1), :488-499)
+ *   X_dev    [N+1][4][B]     nodes (s, v, theta, j); node 0 is x_init (:210)
+ *   U_dev    [N][6][B]       controls and slacks
+ *   J_dev    [B]             objective (:343 accumulated)
+ *   eq_dev   [N][4][B]       continuity of s and v (RK4 end state - next node), theta row, jerk row (:357-376)
+ *   ineq_dev [N][R][B]       R = eepacc_nlp_rows(): every inequality row and bound as  value <= 0
+ *   gradJ_dev [N][10][B]     dJ / d(s_k, v_k, theta_k, j_k, U_k)   (may be NULL)
+ *   jacF_dev  [N][2][3][B]   d(s_end, v_end) / d(v_k, theta_k, Fm_k + Fb_k); d s_end / d s_k = 1  (may be NULL)
+ * `stream` is a hipStream_t (NULL = default stream).  Asynchronous; eepacc_nlp_synchronize waits. */
+int eepacc_nlp_eval(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const double* X_dev, const double* U_dev,
+                    double* J_dev, double* eq_dev, double* ineq_dev, double* gradJ_dev, double* jacF_dev,
+                    void* stream);
+int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -44,147 +44,7 @@ ISO_AMAX = np.array([5.0, 5.0, 3.5, 3.5])
 ISO_JMAG = np.array([5.0, 5.0, 2.5, 2.5])
 
 
-def pwa(x, xs, ys):
-    """Linear interpolation with linear extrapolation; returns (value, slope of the segment used)."""
-    xs = np.asarray(xs, dtype=np.float64)
-    ys = np.asarray(ys, dtype=np.float64)
-    x = np.asarray(x, dtype=np.float64)
-    i = np.clip(np.searchsorted(xs, x, side="right") - 1, 0, len(xs) - 2)
-    dx = xs[i + 1] - xs[i]
-    sl = np.where(dx > 0, (ys[i + 1] - ys[i]) / np.where(dx > 0, dx, 1.0), 0.0)
-    return ys[i] + sl * (x - xs[i]), sl
-
-
-# ----------------------------------------------------------------------------------------------
-# host preprocessing of RunOpt_NLP.m:63-184 (tables)
-# ----------------------------------------------------------------------------------------------
-def _interp_pwa(d, doms, vals):
-    return float(np.interp(d, doms, vals))
-
-
-def min_pwa(Ad, Av, Bd, Bv, simplify):
-    """Functions/PWA_function_manipulation/minPWA.m: pointwise minimum of two PWA functions."""
-    Ad, Av, Bd, Bv = (list(map(float, a)) for a in (Ad, Av, Bd, Bv))
-    if Ad[0] != Bd[0]:
-        if Ad[0] > Bd[0]:
-            Ad, Av = [Bd[0]] + Ad, [Av[0]] + Av
-        else:
-            Bd, Bv = [Ad[0]] + Bd, [Bv[0]] + Bv
-    if Ad[-1] != Bd[-1]:
-        if Ad[-1] > Bd[-1]:
-            Bd, Bv = Bd + [Ad[-1]], Bv + [Bv[-1]]
-        else:
-            Ad, Av = Ad + [Bd[-1]], Av + [Av[-1]]
-    Ad, Av = (list(a) for a in simplify(np.array(Ad), np.array(Av)))
-    Bd, Bv = (list(a) for a in simplify(np.array(Bd), np.array(Bv)))
-    Ad, Av = Ad + [Ad[-1] + 1, Ad[-1] + 2], Av + [Av[-1], Av[-1]]
-    Bd, Bv = Bd + [Bd[-1] + 1, Bd[-1] + 2], Bv + [Bv[-1], Bv[-1]]
-    Cd, Cv = [], []
-    iA = iB = 0
-    doneA = doneB = False
-    while True:
-        Ad1, Av1, Ad2, Av2 = Ad[iA], Av[iA], Ad[iA + 1], Av[iA + 1]
-        Bd1, Bv1, Bd2, Bv2 = Bd[iB], Bv[iB], Bd[iB + 1], Bv[iB + 1]
-        As = (Av2 - Av1) / (Ad2 - Ad1)
-        Bs = (Bv2 - Bv1) / (Bd2 - Bd1)
-        if (Av1 > Bv1 and Av2 < Bv2) or (Av1 < Bv1 and Av2 > Bv2):
-            s1 = (Bv1 - Av1 + (Ad1 - Bd1) * Bs) / (As - Bs)
-            Id = Ad1 + s1
-            if Ad1 <= Id <= Ad2 and Bd1 <= Id <= Bd2:
-                Cd.append(Id)
-                Cv.append(Av1 + As * s1)
-        if Ad2 < Bd2:
-            if Av1 <= _interp_pwa(Ad1, Bd, Bv):
-                Cd.append(Ad1)
-                Cv.append(Av1)
-            iA += 1
-            if iA == len(Ad) - 2:
-                doneA = True
-        else:
-            if Bv1 <= _interp_pwa(Bd1, Ad, Av):
-                Cd.append(Bd1)
-                Cv.append(Bv1)
-            iB += 1
-            if iB == len(Bd) - 2:
-                doneB = True
-        if doneA and doneB:
-            break
-    order = np.argsort(np.array(Cd), kind="stable")
-    return np.array(Cd)[order], np.array(Cv)[order]
-
-
-def saturate_slope_pwa(doms, vals, c_des):
-    """SaturateSlopePWA.m (+ FixCrossingPWA.m between its two passes)."""
-    doms = np.array(doms, dtype=np.float64)
-    vals = np.array(vals, dtype=np.float64)
-
-    def one_pass():
-        for i in range(1, len(doms)):
-            c = (vals[i] - vals[i - 1]) / (doms[i] - doms[i - 1])
-            if c > 0 and c > c_des:
-                doms[i] = doms[i - 1] + (vals[i] - vals[i - 1]) / c_des
-            elif c < 0 and c < -c_des:
-                doms[i - 1] = doms[i] + (vals[i] - vals[i - 1]) / c_des
-    one_pass()
-    d0 = doms.copy()
-    for cc in np.nonzero(np.diff(d0) <= 0)[0]:               # FixCrossingPWA.m (0-based cc = curCross-1)
-        Ad1, Av1, Ad2, Av2 = doms[cc - 1], vals[cc - 1], doms[cc], vals[cc]
-        Bd1, Bv1, Bd2, Bv2 = doms[cc + 1], vals[cc + 1], doms[cc + 2], vals[cc + 2]
-        As = (Av2 - Av1) / (Ad2 - Ad1)
-        Bs = (Bv2 - Bv1) / (Bd2 - Bd1)
-        s1 = (Bv1 - Av1 + (Ad1 - Bd1) * Bs) / (As - Bs)
-        Iv = Av1 + As * s1
-        doms[cc], vals[cc] = d0[cc + 1], Iv
-        doms[cc + 1], vals[cc + 1] = d0[cc], Iv
-    one_pass()
-    return doms, vals
-
-
-def build_tables(OPT: Dict[str, Any]) -> Dict[str, Any]:
-    """Lookup tables of RunOpt_NLP.m:63-184 as plain arrays."""
-    from eepacc_mpc_casadi_matlab_amd.settings import SimplifyPWA
-    T: Dict[str, Any] = {}
-    Ts = float(OPT["Ts"])
-    N = int(round(float(OPT["t_sim"]) / Ts))
-    T["slope"] = (np.asarray(OPT["s_slope"], float), np.asarray(OPT["slope"], float))
-    T["flat"] = bool(np.sum(OPT["slope"]) < 1e-1)                                          # :363
-    T["vlim"] = (np.asarray(OPT["s_speedLim"], float), np.asarray(OPT["v_speedLim"], float))
-    T["curv"] = (np.asarray(OPT["s_curv"], float), np.asarray(OPT["curvature"], float))
-    incr = float(OPT["stopRefDist"]) * float(OPT["stopRefVelSlope"])
-    sS, vS = [], []
-    for loc in np.sort(np.asarray(OPT["stopLoc"], float).ravel()):                         # :95-98
-        sS += [loc - OPT["stopRefDist"], loc, loc + OPT["stopRefDist"]]
-        vS += [incr, float(OPT["stopVel"]), incr]
-    for i in range(len(vS) - 1):                                                           # :101-109
-        if sS[i + 1] <= sS[i]:
-            corr = .5 * (sS[i] - sS[i + 1]) + sS[i + 1]
-            val = incr / (1 + OPT["stopRefDist"] / (sS[i] - sS[i + 1]))
-            vS[i] = vS[i + 1] = val
-            sS[i], sS[i + 1] = corr - 1, corr + 1
-    if len(sS) < 1:
-        sS, vS = [0.0, 1.0], [1e5, 1e5]                                                     # :112-115
-    T["stop"] = (np.array(sS, float), np.array(vS, float))
-    TL = np.asarray(OPT["TLLoc"], float).reshape(-1, 4) if np.size(OPT["TLLoc"]) else np.zeros((0, 4))
-    T["tl_s"] = np.zeros((len(TL), 3))
-    T["tl_v"] = np.array([incr, float(OPT["TLstopVel"]), incr])
-    T["tl_state"] = np.zeros((len(TL), N))
-    for i, row in enumerate(TL):                                                           # :128-156
-        T["tl_s"][i] = [row[0] - OPT["stopRefDist"], row[0], row[0] + OPT["stopRefDist"]]
-        for k in range(N):
-            red = math.fmod(k * Ts - row[1], row[2] + row[3])
-            if red < 0:
-                red += row[2] + row[3]                                                     # MATLAB mod
-            T["tl_state"][i, k] = .2 if red < row[2] else 1e3
-    with np.errstate(divide="ignore"):
-        vc = float(OPT["alpha_TTL"]) * np.abs(T["curv"][1]) ** (-1.0 / 3.0)
-    sI, vI = min_pwa(T["vlim"][0], T["vlim"][1], T["curv"][0], vc, SimplifyPWA)           # :162
-    sI, vI = saturate_slope_pwa(sI, vI, 0.5)                                               # :165
-    keep = np.diff(sI) != 0                            # :168-172 ("~diff(s)==0" parses as (~diff(s))==0; short mask)
-    sI, vI = np.append(sI[:-1][keep], sI[-1]), np.append(vI[:-1][keep], vI[-1])
-    sI, vI = SimplifyPWA(sI, vI)                                                           # :175
-    T["vinc"] = (np.asarray(sI, float), np.asarray(vI, float))
-    T["N"] = N
-    return T
+from eepacc_mpc_casadi_matlab_amd.nlp import pwa, build_tables   # host preprocessing of RunOpt_NLP.m:63-184 (shared, pinned on the saved tables)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,148 @@
+"""GPU parity of the RunOpt_NLP function evaluator (include/eepacc_nlp.h) against the numpy oracle
+(oracle/nlp_oracle.py), through the C-ABI: objective, equality rows, every inequality row, the objective
+gradient and the integrator's Jacobian blocks.  fp64; tolerances: 1e-12 relative on J, 1e-9 absolute on rows
+(values up to 1e5), 1e-9 relative on derivatives (checked against the oracle's jets and against central
+differences of the kernel's own values)."""
+import numpy as np
+import pytest
+
+from conftest import make_case, load_golden
+from oracle import nlp_oracle as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_point(tree, name):
+    OPT, V, s_tv, _ = make_case(tree=tree)
+    G = load_golden(name)
+    P = M.NlpProblem(OPT, V, s_tv)
+    X = np.stack([G["s_opt"], G["v_opt"], G["theta_opt"], G["j_opt"]], axis=1)                    # [N+1][4]
+    U = np.stack([G[k] for k in ("Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt")], axis=1)
+    return OPT, V, P, X, U
+
+
+def _oracle_eval(P, X, U):
+    return P.eval_reference_form(X[:, 0], X[:, 1], X[:, 2], X[:, 3], U)
+
+
+@pytest.mark.parametrize("tree,name", [("ABO", "abo_nlp"), ("ORIG", "orig_nlp")])
+def test_saved_solutions_and_perturbed_batch(tree, name):
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpEvaluator
+    OPT, V, P, X, U = _golden_point(tree, name)
+    ev = NlpEvaluator(OPT, V)
+    N, B = P.N, 7
+    rng = np.random.default_rng(3)
+    Xb = np.repeat(X[:, :, None], B, axis=2)
+    Ub = np.repeat(U[:, :, None], B, axis=2)
+    stv = np.repeat(P.s_tv[:, None], B, axis=1)
+    for i in range(1, B):                                      # instance 0 = the saved point itself
+        Xb[1:, 0, i] += rng.normal(0, 2.0, N)
+        Xb[1:, 1, i] = np.abs(Xb[1:, 1, i] + rng.normal(0, 0.5, N))
+        Xb[1:, 3, i] += rng.normal(0, 0.1, N)
+        Ub[:, 0, i] += rng.normal(0, 200.0, N)
+        Ub[:, 1, i] -= rng.uniform(0, 50.0, N)
+        Ub[:, 2:, i] += rng.uniform(0, 1.0, (N, 4))
+        stv[:, i] += rng.normal(0, 1.0)
+    out = ev.eval(stv, Xb, Ub)
+    ev.synchronize()
+    J, eq, ineq = (out[k].cpu().numpy() for k in ("J", "eq", "ineq"))
+    for i in range(B):
+        P.s_tv = stv[:, i].copy()
+        R = _oracle_eval(P, Xb[:, :, i], Ub[:, :, i])
+        assert abs(J[i] / R["J"] - 1) < 1e-12, (i, J[i], R["J"])
+        assert np.abs(eq[:, :, i] - R["eq"]).max() < 1e-9
+        assert np.abs(ineq[:, :, i] - R["ineq"]).max() < 1e-9 * 1e2        # rows up to 1e5 (power rows, W)
+    # the saved IPOPT point is feasible for the kernel's rows as it is for the oracle's
+    assert np.abs(eq[:, :, 0]).max() < 1e-10 and ineq[:, :, 0].max() < 1e-4
+
+
+def test_gradient_and_integrator_jacobian():
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpEvaluator
+    OPT, V, P, X, U = _golden_point("ABO", "abo_nlp")
+    ev = NlpEvaluator(OPT, V)
+    N = P.N
+    stv = P.s_tv[:, None].copy()
+    X1, U1 = X[:, :, None].copy(), U[:, :, None].copy()
+    base = ev.eval(stv, X1, U1)
+    g = base["gradJ"].cpu().numpy()[:, :, 0]
+    jf = base["jacF"].cpu().numpy()[:, :, :, 0]
+    # oracle: jets of the same integrator (first-order parts)
+    s, v, th = X[:-1, 0], X[:-1, 1], X[:-1, 2]
+    Fm, F = U[:, 0], U[:, 0] + U[:, 1]
+    js, jv = M.Jet.var(s, 0), M.Jet.var(v, 1)
+    jFm, jF = M.Jet.var(Fm, 2), M.Jet.var(F, 3)
+    s1, v1, q = P.rk4(js, jv, jFm, jF, np.cos(th), np.sin(th))
+    W, Ts = P.W, P.Ts
+    np.testing.assert_allclose(g[:, 1], q.g[1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(g[:, 4], q.g[2] + q.g[3], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(g[:, 5], q.g[3], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(g[:, 3], Ts * 2 * W[2] * X[:-1, 3], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g[:, 6:], np.column_stack([np.full(N, Ts * W[3]), Ts * W[4] * (2 * U[:, 3] + 1e2),
+                                                          np.full(N, Ts * W[5]), np.full(N, Ts * W[6])]), rtol=1e-12)
+    np.testing.assert_allclose(jf[:, 0, 0], s1.g[1], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(jf[:, 0, 2], s1.g[3], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(jf[:, 1, 0], v1.g[1], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(jf[:, 1, 2], v1.g[3], rtol=1e-9, atol=1e-15)
+    # central differences of the kernel's own outputs (theta included, which the oracle's jets do not carry).
+    # Node k (k < N) or control k of EVERY interval is shifted at once: the objective moves by the sum of the stage
+    # gradients; continuity row k moves by its own integrator block, and the v row also by -1 where node k+1 moved
+    def shifted(col, d, is_u):
+        Xs, Us = X1.copy(), U1.copy()
+        if is_u:
+            Us[:, col, 0] += d
+        else:
+            Xs[:-1, col, 0] += d
+        o = ev.eval(stv, Xs, Us, want_grad=False)
+        return o["J"].cpu().numpy()[0], o["eq"].cpu().numpy()[:, :, 0]
+    moved_next = np.concatenate([np.ones(N - 1), [0.0]])
+    for col, is_u, h, gi, k in ((1, False, 1e-4, 1, 0), (2, False, 1e-5, 2, 1), (0, True, 1e-1, 4, 2)):
+        Jp, ep = shifted(col, h, is_u)
+        Jm, em = shifted(col, -h, is_u)
+        fd = (Jp - Jm) / (2 * h)
+        assert abs(fd - g[:, gi].sum()) <= 1e-6 * abs(g[:, gi]).sum() + 1e-6, (col, fd, g[:, gi].sum())
+        des = (ep[:, 0] - em[:, 0]) / (2 * h)
+        dev = (ep[:, 1] - em[:, 1]) / (2 * h) + (moved_next if (not is_u and col == 1) else 0.0)
+        np.testing.assert_allclose(des, jf[:, 0, k], rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(dev, jf[:, 1, k], rtol=2e-6, atol=2e-7)
+
+
+def test_route_features_batch_and_determinism():
+    """Stops, a traffic light, a curve and slopes: every lookup table in play, 64 routes with different lead traces."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpEvaluator
+    from eepacc_mpc_casadi_matlab_amd.settings import GenerateUseCase
+    OPT, V, s_tv, _ = make_case(tree="ABO", stopLoc=np.array([400.0]), TLLoc=np.array([[800.0, 5.0, 20.0, 30.0]]),
+                                curves=np.array([[0.02, 1500.0, 1600.0]]), slopes=np.array([[8.0, 2000.0, 2200.0]]),
+                                s_goal=5000.0)
+    OPT = GenerateUseCase(OPT)
+    P = M.NlpProblem(OPT, V, s_tv)
+    assert not P.T["flat"] and P.n_tl == 1
+    ev = NlpEvaluator(OPT, V)
+    assert ev.R == P.n_rows == 17 + 2 + 11
+    N, B = P.N, 64
+    rng = np.random.default_rng(11)
+    X = np.zeros((N + 1, 4, B))
+    U = np.zeros((N, 6, B))
+    X[:, 1] = rng.uniform(0, 25, (N + 1, B))
+    X[:, 0] = np.cumsum(X[:, 1] * 0.5, axis=0)
+    X[:, 2] = rng.normal(0, 0.02, (N + 1, B))
+    X[:, 3] = rng.normal(0, 0.5, (N + 1, B))
+    U[:, 0] = rng.uniform(-3000, 3000, (N, B))
+    U[:, 1] = -rng.uniform(0, 500, (N, B))
+    U[:, 2:] = rng.uniform(0, 3, (N, 4, B))
+    stv = np.cumsum(rng.uniform(0, 12, (N, B)), axis=0) + 10.0
+    o1 = ev.eval(stv, X, U)
+    J1, e1, r1, g1 = (o1[k].cpu().numpy().copy() for k in ("J", "eq", "ineq", "gradJ"))
+    o2 = ev.eval(stv, X, U)
+    for a, k in ((J1, "J"), (e1, "eq"), (r1, "ineq"), (g1, "gradJ")):
+        assert np.array_equal(a, o2[k].cpu().numpy()), k                     # bit-reproducible
+    for i in (0, 17, 63):
+        P.s_tv = stv[:, i].copy()
+        R = _oracle_eval(P, X[:, :, i], U[:, :, i])
+        assert abs(J1[i] / R["J"] - 1) < 1e-12
+        assert np.abs(e1[:, :, i] - R["eq"]).max() < 1e-9
+        assert np.abs(r1[:, :, i] - R["ineq"]).max() < 1e-6                   # rows up to 1e6 (random forces x speeds)
+    # permutation of the routes permutes the outputs (no cross-route coupling)
+    perm = rng.permutation(B)
+    o3 = ev.eval(stv[:, perm], X[:, :, perm], U[:, :, perm])
+    assert np.array_equal(o3["J"].cpu().numpy(), J1[perm])
+    assert np.array_equal(o3["ineq"].cpu().numpy(), r1[:, :, perm])
