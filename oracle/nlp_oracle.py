@@ -416,7 +416,7 @@ def _linearize(P: NlpProblem, chi, u, lam, nu, sigma):
     return dict(cost=cost, f=f, r=r, Jr=Jr, AB=AB, gl=gl, Hl=Hl, Gc=Gc)
 
 
-REG_SCALE = np.array([1e-6, 1e-6, 1e-2, 1e-2, 1.0, 1.0])     # Levenberg term on the controls, per unit^2
+REG_SCALE = np.array([1e-6, 1e-6, 1e-10, 1e-10, 1e-10, 1e-10])   # Levenberg term on the forces (per N^2); the slacks enter convexly
 
 
 def _riccati(Q, q, AB, c, reg):

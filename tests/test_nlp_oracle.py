@@ -125,3 +125,35 @@ def test_interior_point_solver_short_routes(t_sim, iters):
     ref = P.eval_reference_form(chi[:, 0], chi[:, 1], np.zeros(P.N + 1), chi[:, 3], u)
     assert np.abs(ref["eq"]).max() < 1e-9
     assert abs(ref["J"] / R["J"] - 1) < 1e-12
+
+
+def test_saved_solution_is_a_kkt_point_of_the_restated_nlp():
+    """Optimality pin (the saved file has no multipliers): started from the saved controls (states re-integrated, slacks
+    1e-3 above what the rows need, barrier 1e-4) the interior-point solver converges in a few Newton-type iterations to
+    a KKT point (1e-7, scaled problem) whose objective equals the saved point's to 1e-6 relative (measured 2.6e-7:
+    IPOPT's own termination tolerance) and whose trajectory stays within 0.05 m/s of the saved one.  A wrong objective
+    gradient, integrator sensitivity or row Jacobian would move the point away."""
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    P = M.NlpProblem(OPT, V, s_tv)
+    G = load_golden("abo_nlp")
+    N = P.N
+    u = np.zeros((N, 6))
+    u[:, 0] = G["Fm_opt"]
+    u[:, 1] = np.minimum(G["Fb_opt"], -1e-3)
+    chi0 = np.zeros((N + 1, 4))
+    chi0[0, 2] = -P.drag(0.0, 0.0) / (V["lambda"] * V["m"])
+    chi, _ = M.rollout(P, chi0, u, chi0, None, None, 0.0)
+    z = np.zeros((N, 6))
+    z[:, :2] = u[:, :2]
+    r0 = M._rows(P, chi[1:], z, np.arange(N))[0]
+    u[:, 2] = np.maximum(r0[:, 13], 0) + 1e-3
+    u[:, 3] = np.maximum(r0[:, 16], 0) + 1e-3
+    u[:, 4] = np.maximum(np.maximum(r0[:, 12], r0[:, 15]), 0) + 1e-3
+    u[:, 5] = np.maximum(np.max(r0[:, 0:12], axis=1), 0) + 1e-3
+    R = M.solve(P, M.NlpOptions(max_iter=60, mu_init=1e-4), start=(chi, u))
+    assert R["status"] == 0 and R["iters"] <= 40
+    U = np.stack([G[k] for k in ("Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt")], axis=1)
+    J_saved = P.eval_reference_form(G["s_opt"], G["v_opt"], G["theta_opt"], G["j_opt"], U)["J"]
+    assert abs(R["J"] / J_saved - 1) < 1e-6
+    assert np.abs(R["chi"][:, 1] - G["v_opt"]).max() < 0.05
+    assert np.abs(R["chi"][:, 0] - G["s_opt"]).max() < 0.5
