@@ -47,6 +47,29 @@ ISO_JMAG = np.array([5.0, 5.0, 2.5, 2.5])
 from eepacc_mpc_casadi_matlab_amd.nlp import pwa, build_tables   # host preprocessing of RunOpt_NLP.m:63-184 (shared, pinned on the saved tables)
 
 
+def pwa_smooth(x, xs, ys, eps):
+    """The lookup convolved with a box of half-width eps (eps = 0: the lookup itself): value, slope, curvature.
+    With F the antiderivative of the piecewise-linear f:  f_eps = (F(x+eps) - F(x-eps)) / (2 eps), C^1 with bounded
+    curvature.  Used by the solver's graduated smoothing only; the problem that is pinned and reported is eps = 0."""
+    if eps <= 0.0:
+        v, sl = pwa(x, xs, ys)
+        return v, sl, np.zeros_like(v)
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    dxs = np.diff(xs)
+    seg_sl = np.where(dxs > 0, np.diff(ys) / np.where(dxs > 0, dxs, 1.0), 0.0)
+    C = np.concatenate([[0.0], np.cumsum(0.5 * (ys[1:] + ys[:-1]) * dxs)])
+
+    def F_f_df(z):
+        i = np.clip(np.searchsorted(xs, z, side="right") - 1, 0, len(xs) - 2)
+        d = z - xs[i]
+        return C[i] + ys[i] * d + 0.5 * seg_sl[i] * d * d, ys[i] + seg_sl[i] * d, seg_sl[i]
+    Fp, fp, dp = F_f_df(x + eps)
+    Fm, fm, dm = F_f_df(x - eps)
+    return (Fp - Fm) / (2 * eps), (fp - fm) / (2 * eps), (dp - dm) / (2 * eps)
+
+
 # ----------------------------------------------------------------------------------------------
 # second-order jets over (s_k, v_k, Fm_k, F_k)
 # ----------------------------------------------------------------------------------------------
@@ -117,6 +140,7 @@ class NlpProblem:
         self.Fm_max = V["phi"] * V["T_m_max"] * V["eta_TF"]
         self.n_tl = self.T["tl_s"].shape[0]
         self.n_rows = 17 + 2 * self.n_tl + 10 + (1 if math.isfinite(self.s_goal) else 0)
+        self.eps_s = self.eps_v = 0.0        # graduated smoothing of the lookups in position / speed (solver only)
 
     # ---- model pieces --------------------------------------------------------------------------
     def theta(self, s):
@@ -264,6 +288,8 @@ class NlpOptions:
         self.mu_min = 1e-9
         self.kappa_eps = 10.0
         self.kappa_mu = 0.2
+        self.kappa_sigma = 1e10      # multipliers are kept within this factor of mu / t: the slacks follow their rows (primal),
+                                     # so the barrier curvature the merit sees is mu / t^2
         self.theta_mu = 1.5
         self.tol = 1e-7
         self.tau_min = 0.99
@@ -309,28 +335,38 @@ def _rows(P: NlpProblem, chi1, u, k_idx):
     r[:, i] = kF * Fm - rear - xf; G[:, i, IFM] = kF; G[:, i, IP] = -V["h_g"] * V["lambda"]
     G[:, i, IV] = -2 * kz * v; G[:, i, IS] = -drear_s; G[:, i, IXF] = -1
     curv.append((i, IV, IV, np.full(n, -2 * kz))); i += 1
-    amin, damin = pwa(v, ISO_V, ISO_AMIN)
-    amax, damax = pwa(v, ISO_V, ISO_AMAX)
-    jm, djm = pwa(v, ISO_V, ISO_JMAG)
-    r[:, i] = -(p - amin + xf); G[:, i, IP] = -1; G[:, i, IV] = damin; G[:, i, IXF] = -1; i += 1
-    r[:, i] = p - amax - xf; G[:, i, IP] = 1; G[:, i, IV] = -damax; G[:, i, IXF] = -1; i += 1
-    r[:, i] = -(j + jm + xf); G[:, i, IJ] = -1; G[:, i, IV] = -djm; G[:, i, IXF] = -1; i += 1
-    r[:, i] = j - jm - xf; G[:, i, IJ] = 1; G[:, i, IV] = -djm; G[:, i, IXF] = -1; i += 1
-    vl, dvl = pwa(s, *P.T["vlim"])
-    r[:, i] = v - vl - xf; G[:, i, IV] = 1; G[:, i, IS] = -dvl; G[:, i, IXF] = -1; i += 1
-    c, dc = pwa(s, *P.T["curv"])
+    es, evv = P.eps_s, P.eps_v
+    amin, damin, camin = pwa_smooth(v, ISO_V, ISO_AMIN, evv)
+    amax, damax, camax = pwa_smooth(v, ISO_V, ISO_AMAX, evv)
+    jm, djm, cjm = pwa_smooth(v, ISO_V, ISO_JMAG, evv)
+    r[:, i] = -(p - amin + xf); G[:, i, IP] = -1; G[:, i, IV] = damin; G[:, i, IXF] = -1
+    curv.append((i, IV, IV, camin)); i += 1
+    r[:, i] = p - amax - xf; G[:, i, IP] = 1; G[:, i, IV] = -damax; G[:, i, IXF] = -1
+    curv.append((i, IV, IV, -camax)); i += 1
+    r[:, i] = -(j + jm + xf); G[:, i, IJ] = -1; G[:, i, IV] = -djm; G[:, i, IXF] = -1
+    curv.append((i, IV, IV, -cjm)); i += 1
+    r[:, i] = j - jm - xf; G[:, i, IJ] = 1; G[:, i, IV] = -djm; G[:, i, IXF] = -1
+    curv.append((i, IV, IV, -cjm)); i += 1
+    vl, dvl, cvl = pwa_smooth(s, *P.T["vlim"], es)
+    r[:, i] = v - vl - xf; G[:, i, IV] = 1; G[:, i, IS] = -dvl; G[:, i, IXF] = -1
+    curv.append((i, IS, IS, -cvl)); i += 1
+    c, dc, _ = pwa_smooth(s, *P.T["curv"], es)
     ac = np.maximum(np.abs(c), 1e-300)
     r[:, i] = v - P.alpha * ac ** (-1.0 / 3.0) - xf; G[:, i, IV] = 1
     G[:, i, IS] = P.alpha / 3.0 * ac ** (-4.0 / 3.0) * np.sign(c) * dc; G[:, i, IXF] = -1; i += 1
-    sv, dsv = pwa(s, *P.T["stop"])
-    r[:, i] = v - sv - xs; G[:, i, IV] = 1; G[:, i, IS] = -dsv; G[:, i, IXS] = -1; i += 1
+    sv, dsv, csv_ = pwa_smooth(s, *P.T["stop"], es)
+    r[:, i] = v - sv - xs; G[:, i, IV] = 1; G[:, i, IS] = -dsv; G[:, i, IXS] = -1
+    curv.append((i, IS, IS, -csv_)); i += 1
     for t in range(P.n_tl):
-        tv, dtv = pwa(s, P.T["tl_s"][t], P.T["tl_v"])
+        tv, dtv, ctv = pwa_smooth(s, P.T["tl_s"][t], P.T["tl_v"], es)
         tt = P.T["tl_state"][t][k_idx]
-        r[:, i] = v - tv - tt - xs; G[:, i, IV] = 1; G[:, i, IS] = -dtv; G[:, i, IXS] = -1; i += 1
-        r[:, i] = -(v + tv + 1e3 - 10 - tt + xs); G[:, i, IV] = -1; G[:, i, IS] = -dtv; G[:, i, IXS] = -1; i += 1
-    vi, dvi = pwa(s, *P.T["vinc"])
-    r[:, i] = -(v - vi + xv); G[:, i, IV] = -1; G[:, i, IS] = dvi; G[:, i, IXV] = -1; i += 1
+        r[:, i] = v - tv - tt - xs; G[:, i, IV] = 1; G[:, i, IS] = -dtv; G[:, i, IXS] = -1
+        curv.append((i, IS, IS, -ctv)); i += 1
+        r[:, i] = -(v + tv + 1e3 - 10 - tt + xs); G[:, i, IV] = -1; G[:, i, IS] = -dtv; G[:, i, IXS] = -1
+        curv.append((i, IS, IS, -ctv)); i += 1
+    vi, dvi, cvi = pwa_smooth(s, *P.T["vinc"], es)
+    r[:, i] = -(v - vi + xv); G[:, i, IV] = -1; G[:, i, IS] = dvi; G[:, i, IXV] = -1
+    curv.append((i, IS, IS, cvi)); i += 1
     stv = P.s_tv[k_idx]
     r[:, i] = s - (stv - P.h_min); G[:, i, IS] = 1; i += 1
     r[:, i] = s + P.tau_min * v - xs - stv; G[:, i, IS] = 1; G[:, i, IV] = P.tau_min; G[:, i, IXS] = -1; i += 1
@@ -643,13 +679,13 @@ def solve(P: NlpProblem, opt: NlpOptions | None = None, start=None):
         if not accepted:
             status = 2
             break
-        reg_last = reg / 3.0 if ls == 0 else reg
+        reg_last = reg / 3.0 if ls <= 1 else reg
         if reg_last < o.reg_first:
             reg_last = 0.0
         chi, u, t = chi_t, u_t, t_t
         cost = cost_t
         lam = lam + a_d * dlam
-        lam = np.clip(lam, mu / (1e10 * t), 1e10 * mu / t)
+        lam = np.clip(lam, mu / (o.kappa_sigma * t), o.kappa_sigma * mu / t)
         if o.verbose:
             print("   a_p %.2e a_d %.2e alpha %.2e%s |du| %.2e |dchi| %.2e" %
                   (a_p, a_d, a, "" if accepted else " (not accepted)", np.abs(du).max(), np.abs(dchi).max()))

@@ -66,18 +66,22 @@ def test_pwa_tables_with_route_features():
     assert P.n_rows == 17 + 2 + 10
 
 
-def test_derivatives_against_finite_differences():
+@pytest.mark.parametrize("eps", [(0.0, 0.0), (3.0, 1.5)])
+def test_derivatives_against_finite_differences(eps):
+    """eps > 0: the graduated smoothing of the lookups the solver may use (value, slope and curvature of the
+    box-filtered tables); eps = 0 is the problem itself."""
     P = _problem("ABO", t_sim=5.0)
+    P.eps_s, P.eps_v = eps
     N = P.N
     rng = np.random.default_rng(0)
-    chi = np.column_stack([rng.uniform(1, 3, N + 1), rng.uniform(6, 8, N + 1), rng.uniform(-1, 1, N + 1),
-                           rng.uniform(-1, 1, N + 1)])
+    chi = np.column_stack([rng.uniform(1, 3, N + 1) + (995.0 if eps[0] > 0 else 0.0), rng.uniform(4, 8, N + 1),
+                           rng.uniform(-1, 1, N + 1), rng.uniform(-1, 1, N + 1)])
     u = np.column_stack([rng.uniform(200, 900, N), -rng.uniform(1, 50, N), rng.uniform(.1, 1, (N, 4))])
     lam = rng.uniform(.1, 1, (N, P.n_rows))
     nu = rng.uniform(-1, 1, (N + 1, 4))
     sig = 1e-5
     D = M._linearize(P, chi, u, lam, nu, sig)
-    eps = 1e-6
+    eps = 1e-6          # (shadows the parameter on purpose: finite-difference step from here on)
 
     def shifted(idx, d, next_state):
         c, w = chi.copy(), u.copy()
@@ -92,7 +96,7 @@ def test_derivatives_against_finite_differences():
         c1, f1, _ = M._stage_values(P, cp, up, sig)
         c0, f0, _ = M._stage_values(P, cm, um, sig)
         assert np.abs((c1 - c0) / (2 * eps) - D["gl"][:, idx]).max() < 1e-6
-        assert np.abs((f1 - f0) / (2 * eps) - D["AB"][:, :, idx]).max() < 1e-8
+        assert np.abs((f1 - f0) / (2 * eps) - D["AB"][:, :, idx]).max() < 5e-7       # central differences at s ~ 1e3
         g1 = M._linearize(P, cp, up, lam, nu, sig)
         g0 = M._linearize(P, cm, um, lam, nu, sig)
         H = ((g1["gl"] + np.einsum("nxi,nx->ni", g1["AB"], nu[1:]))
