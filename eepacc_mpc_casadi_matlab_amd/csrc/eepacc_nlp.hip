@@ -222,6 +222,177 @@ k_nlp_sum(int N, int B, const double* __restrict__ q_stage, double* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Riccati sweep of one Newton system per route (include/eepacc_nlp.h: eepacc_nlp_riccati).  One wavefront per route.
+// Per stage: M = Q + AB' P AB and m = q + AB'(P c + p) entry-parallel over the lanes through LDS; the 6 x 6 control
+// block is factorised redundantly in every lane (registers, no communication), lanes 0..4 back-substitute one
+// right-hand side each (the four state columns and the gradient); P, p of the stage entry-parallel again.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RX = 4, RU = 6, RY = 10;
+struct RicScale { double s[RU]; };
+
+__global__ void __launch_bounds__(64)
+k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict__ qg, const double* __restrict__ ABg,
+          const double* __restrict__ cg, const double* __restrict__ regg, const RicScale sc, double* __restrict__ dchi,
+          double* __restrict__ du, double* __restrict__ nu, double* __restrict__ work, int32_t* __restrict__ status) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= B) return;
+    __shared__ double M[RY][RY], m[RY], AB[RX][RY], W[RX][RY], P[RX][RX], pv[RX], pc[RX], cvec[RX], Kk[RU][RX + 1];
+    const double reg = regg[r];
+    const double* Qr = Qg + (size_t)r * N * 100;
+    const double* qr = qg + (size_t)r * N * 10;
+    const double* ABr = ABg + (size_t)r * N * 40;
+    const double* cr = cg + (size_t)r * N * 4;
+    double* wr = work + (size_t)r * N * 50;
+    if (lane < 16) P[lane >> 2][lane & 3] = 0.0;
+    if (lane < 4) pv[lane] = 0.0;
+    int bad = 0;
+    __syncthreads();
+    // stage data travel global -> registers -> LDS one stage ahead of the arithmetic (the sweep is a chain of dependent
+    // stages: a load issued at the top of its own stage would put the whole memory latency on the critical path)
+    double pre0, pre1 = 0.0, pre2 = 0.0;
+    auto prefetch = [&](int k) {
+        pre0 = Qr[(size_t)k * 100 + lane];
+        if (lane < 36) pre1 = Qr[(size_t)k * 100 + 64 + lane];
+        if (lane < 40) pre2 = ABr[(size_t)k * 40 + lane];
+        else if (lane < 50) pre2 = qr[(size_t)k * 10 + lane - 40];
+        else if (lane < 54) pre2 = cr[(size_t)k * 4 + lane - 50];
+    };
+    prefetch(N - 1);
+    for (int k = N - 1; k >= 0; --k) {
+        M[lane / 10][lane % 10] = pre0;
+        if (lane < 36) M[(64 + lane) / 10][(64 + lane) % 10] = pre1;
+        if (lane < 40) AB[lane / 10][lane % 10] = pre2;
+        else if (lane < 50) m[lane - 40] = pre2;
+        else if (lane < 54) cvec[lane - 50] = pre2;
+        __syncthreads();
+        if (k > 0) prefetch(k - 1);
+        if (lane < 40) {                                   // W = P AB
+            const int x = lane / 10, j = lane % 10;
+            W[x][j] = P[x][0] * AB[0][j] + P[x][1] * AB[1][j] + P[x][2] * AB[2][j] + P[x][3] * AB[3][j];
+        } else if (lane < 44) {                            // pc = P c + p
+            const int x = lane - 40;
+            pc[x] = P[x][0] * cvec[0] + P[x][1] * cvec[1] + P[x][2] * cvec[2] + P[x][3] * cvec[3] + pv[x];
+        }
+        __syncthreads();
+        for (int e = lane; e < 100; e += 64) {             // M = Q + AB' W (+ Levenberg term on the controls)
+            const int i = e / 10, j = e % 10;
+            double acc = M[i][j] + AB[0][i] * W[0][j] + AB[1][i] * W[1][j] + AB[2][i] * W[2][j] + AB[3][i] * W[3][j];
+            if (i == j && i >= RX) acc += reg * sc.s[i - RX];
+            M[i][j] = acc;
+        }
+        if (lane < 10) m[lane] += AB[0][lane] * pc[0] + AB[1][lane] * pc[1] + AB[2][lane] * pc[2] + AB[3][lane] * pc[3];
+        __syncthreads();
+        // Cholesky of the control block, redundantly per lane; per-pivot relative test
+        double L[RU][RU], invd[RU];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < RU; ++i) {
+            double d = M[RX + i][RX + i];
+            const double d0 = d;
+#pragma unroll
+            for (int t = 0; t < i; ++t) d -= L[i][t] * L[i][t];
+            if (!(d > 1e-10 * fabs(d0))) { ok = false; d = 1.0; }
+            const double li = sqrt(d), inv = 1.0 / li;
+            L[i][i] = li;
+            invd[i] = inv;
+#pragma unroll
+            for (int j2 = i + 1; j2 < RU; ++j2) {
+                double v = 0.5 * (M[RX + j2][RX + i] + M[RX + i][RX + j2]);
+#pragma unroll
+                for (int t = 0; t < i; ++t) v -= L[j2][t] * L[i][t];
+                L[j2][i] = v * inv;
+            }
+        }
+        if (!ok && bad == 0) bad = 1 + (N - 1 - k);
+        if (lane < RX + 1) {                               // K = -Muu^-1 Mux (lanes 0..3), kf = -Muu^-1 m_u (lane 4)
+            double y[RU];
+#pragma unroll
+            for (int i = 0; i < RU; ++i) {
+                double v = lane < RX ? M[RX + i][lane] : m[RX + i];
+#pragma unroll
+                for (int t = 0; t < i; ++t) v -= L[i][t] * y[t];
+                y[i] = v * invd[i];
+            }
+#pragma unroll
+            for (int i = RU - 1; i >= 0; --i) {
+                double v = y[i];
+#pragma unroll
+                for (int t = i + 1; t < RU; ++t) v -= L[t][i] * y[t];
+                y[i] = v * invd[i];
+            }
+#pragma unroll
+            for (int i = 0; i < RU; ++i) Kk[i][lane] = -y[i];
+        }
+        __syncthreads();
+        // P = sym(Mxx + Mxu K), p = m_x + Mxu kf; gains and value function of the stage -> work (30 + 16 + 4)
+        double Pn = 0.0, pn = 0.0;
+        if (lane < 16) {
+            const int a = lane >> 2, b = lane & 3;
+            double t1 = M[a][b], t2 = M[b][a];
+#pragma unroll
+            for (int t = 0; t < RU; ++t) { t1 += M[a][RX + t] * Kk[t][b]; t2 += M[b][RX + t] * Kk[t][a]; }
+            Pn = 0.5 * (t1 + t2);
+        } else if (lane < 20) {
+            const int a = lane - 16;
+            pn = m[a];
+#pragma unroll
+            for (int t = 0; t < RU; ++t) pn += M[a][RX + t] * Kk[t][RX];
+        }
+        if (lane < 30) wr[(size_t)k * 50 + lane] = Kk[lane / 5][lane % 5];
+        __syncthreads();
+        if (lane < 16) { P[lane >> 2][lane & 3] = Pn; wr[(size_t)k * 50 + 30 + lane] = Pn; }
+        else if (lane < 20) { pv[lane - 16] = pn; wr[(size_t)k * 50 + 46 + lane - 16] = pn; }
+    }
+    __syncthreads();
+    // forward sweep: lanes 0..3 carry dchi, lanes 0..5 compute du through LDS
+    __shared__ double x[RX], uu[RU];
+    double* dcr = dchi + (size_t)r * (N + 1) * 4;
+    double* dur = du + (size_t)r * N * 6;
+    double* nur = nu + (size_t)r * (N + 1) * 4;
+    if (lane < RX) { x[lane] = 0.0; dcr[lane] = 0.0; nur[lane] = 0.0; nur[(size_t)N * 4 + lane] = 0.0; }
+    __syncthreads();
+    __shared__ double Kf[50];                              // the stage's work block: K | kf (30), P (16), p (4)
+    double f0 = 0.0, f1 = 0.0;
+    auto prefetch_f = [&](int k) {
+        if (lane < 40) f0 = ABr[(size_t)k * 40 + lane];
+        else if (lane < 44) f0 = cr[(size_t)k * 4 + lane - 40];
+        if (lane < 50) f1 = wr[(size_t)k * 50 + lane];
+    };
+    prefetch_f(0);
+    for (int k = 0; k < N; ++k) {
+        if (lane < 40) AB[lane / 10][lane % 10] = f0;
+        else if (lane < 44) cvec[lane - 40] = f0;
+        if (lane < 50) Kf[lane] = f1;
+        __syncthreads();
+        if (k + 1 < N) prefetch_f(k + 1);
+        if (lane < RU) {                                   // du_k = K_k dchi_k + kf_k
+            const double* Kr = Kf + lane * 5;
+            const double v = Kr[0] * x[0] + Kr[1] * x[1] + Kr[2] * x[2] + Kr[3] * x[3] + Kr[4];
+            uu[lane] = v;
+            dur[(size_t)k * 6 + lane] = v;
+        } else if (lane >= 8 && lane < 12 && k > 0) {      // costate nu_k = P_k dchi_k + p_k
+            const int a2 = lane - 8;
+            const double* Pk = Kf + 30;
+            nur[(size_t)k * 4 + a2] = Pk[a2 * 4 + 0] * x[0] + Pk[a2 * 4 + 1] * x[1] + Pk[a2 * 4 + 2] * x[2] + Pk[a2 * 4 + 3] * x[3] + Pk[16 + a2];
+        }
+        __syncthreads();
+        double xn = 0.0;
+        if (lane < RX) {
+            xn = cvec[lane];
+#pragma unroll
+            for (int t = 0; t < RX; ++t) xn += AB[lane][t] * x[t];
+#pragma unroll
+            for (int t = 0; t < RU; ++t) xn += AB[lane][RX + t] * uu[t];
+        }
+        __syncthreads();
+        if (lane < RX) { x[lane] = xn; dcr[(size_t)(k + 1) * 4 + lane] = xn; }
+        __syncthreads();
+    }
+    if (lane == 0) status[r] = bad;
+}
+
 }  // namespace
 
 struct eepacc_nlp_handle {
@@ -334,5 +505,24 @@ extern "C" int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream) {
     if (!h) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_synchronize: null handle");
     NLPCHK(hipSetDevice(h->device));
     NLPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev, const double* q_dev, const double* AB_dev,
+                                  const double* c_dev, const double* reg_dev, const double reg_scale[6], double* dchi_dev,
+                                  double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, void* stream) {
+    if (B < 1 || N < 1 || !Q_dev || !q_dev || !AB_dev || !c_dev || !reg_dev || !reg_scale || !dchi_dev || !du_dev || !nu_dev ||
+        !work_dev || !status_dev)
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_riccati: null argument, B < 1 or N < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return eepacc::set_error(EEPACC_EDEVICE, "eepacc_nlp_riccati: no HIP device (libeepacc has no CPU path)");
+    if (device < 0 || device >= ndev) return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_riccati: bad device index");
+    NLPCHK(hipSetDevice(device));
+    RicScale sc;
+    for (int i = 0; i < 6; ++i) sc.s[i] = reg_scale[i];
+    hipLaunchKernelGGL(k_riccati, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, Q_dev, q_dev, AB_dev, c_dev, reg_dev, sc,
+                       dchi_dev, du_dev, nu_dev, work_dev, status_dev);
+    NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }

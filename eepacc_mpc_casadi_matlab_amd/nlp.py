@@ -19,7 +19,7 @@ import numpy as np
 
 from ._abi import Vehicle, make_vehicle
 
-__all__ = ["pwa", "build_tables", "NlpEvaluator", "nlp_rows", "postprocess"]
+__all__ = ["pwa", "build_tables", "NlpEvaluator", "nlp_rows", "postprocess", "riccati_batched"]
 
 
 def pwa(x, xs, ys):
@@ -194,6 +194,7 @@ def _bind(lib):
     lib.eepacc_nlp_destroy.restype = None
     lib.eepacc_nlp_eval.argtypes = [vp, C.c_int] + [vp] * 9
     lib.eepacc_nlp_synchronize.argtypes = [vp, vp]
+    lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -297,6 +298,35 @@ class NlpEvaluator:
         rc = self.lib.eepacc_nlp_synchronize(self.h, stream)
         if rc != 0:
             raise self._err("eepacc_nlp_synchronize failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+
+
+def riccati_batched(Q, q, AB, c, reg, reg_scale=(1e-6, 1e-6, 1e-10, 1e-10, 1e-10, 1e-10), device: int = 0):
+    """include/eepacc_nlp.h: eepacc_nlp_riccati.  Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4], reg [B]
+    (numpy or CUDA tensors).  Returns (dchi [B][N+1][4], du [B][N][6], nu [B][N+1][4], status [B]) as CUDA tensors."""
+    import torch
+    from .engine import load_library, EepaccError
+    lib = _bind(load_library())
+    dev = torch.device("cuda", device)
+
+    def d(x):
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+        return t.to(device=dev, dtype=torch.float64).contiguous()
+    Q, q, AB, c, reg = d(Q), d(q), d(AB), d(c), d(reg)
+    B, N = int(Q.shape[0]), int(Q.shape[1])
+    assert Q.shape == (B, N, 10, 10) and q.shape == (B, N, 10) and AB.shape == (B, N, 4, 10) and c.shape == (B, N, 4)
+    assert reg.shape == (B,)
+    dchi = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
+    du = torch.empty((B, N, 6), dtype=torch.float64, device=dev)
+    nu = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
+    work = torch.empty((B, N, 50), dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    sc = (C.c_double * 6)(*[float(x) for x in reg_scale])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.eepacc_nlp_riccati(device, B, N, Q.data_ptr(), q.data_ptr(), AB.data_ptr(), c.data_ptr(), reg.data_ptr(), sc,
+                                dchi.data_ptr(), du.data_ptr(), nu.data_ptr(), work.data_ptr(), status.data_ptr(), stream)
+    if rc != 0:
+        raise EepaccError("eepacc_nlp_riccati failed (%d): %s" % (rc, lib.eepacc_last_error().decode()))
+    return dchi, du, nu, status
 
 
 def postprocess(OPTsettings: Dict[str, Any], V: Dict[str, float], v_opt, Fm_opt, j_opt=None, slacks=None):

@@ -84,6 +84,23 @@ int eepacc_nlp_eval(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const d
                     void* stream);
 int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream);
 
+/* Stage-wise factorisation of one Newton system per route: the linear solve inside every interior-point iteration
+ * (what IPOPT hands to MUMPS in the reference, RunOpt_NLP.m:505-510), exploiting that the problem is an optimal-control
+ * problem: with chi = (s, v, p, j), u = the six controls / slacks and w_k = (chi_k, u_k) it solves
+ *     min  sum_k  1/2 w_k' Q_k w_k + q_k' w_k     s.t.  dchi_{k+1} = AB_k w_k + c_k,  dchi_0 = 0
+ * by the Riccati recursion (backward sweep over the N stages, forward sweep for the step and the costates).  The sweep
+ * is the only serial part of an iteration: one wavefront per route walks the stages, routes run side by side.
+ *   Q_dev  [B][N][10][10]  stage Hessians (symmetric, both triangles), q_dev [B][N][10], AB_dev [B][N][4][10],
+ *   c_dev  [B][N][4]       (route-major: a wavefront streams its own route's stages)
+ *   reg_dev [B]            Levenberg term of the route; reg * reg_scale[i] is added to the diagonal of control i
+ *   dchi_dev [B][N+1][4], du_dev [B][N][6], nu_dev [B][N+1][4]   step and costates (nu_0 and nu_N are 0)
+ *   work_dev [B][N][50]    gains and value-function blocks between the two sweeps
+ *   status_dev [B]         0, or 1 + the first stage (counted from the end) whose control block is not positive definite
+ *                          (pivot <= 1e-10 x its diagonal entry): the caller raises reg and calls again */
+int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev, const double* q_dev, const double* AB_dev,
+                       const double* c_dev, const double* reg_dev, const double reg_scale[6], double* dchi_dev,
+                       double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

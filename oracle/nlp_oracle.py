@@ -535,6 +535,27 @@ def rollout(P: NlpProblem, chi, u, chi_base, K, kf, alpha):
     return cn, un
 
 
+def assemble_newton(P: NlpProblem, chi, u, lam, t, nu, mu, sigma):
+    """Stage data of the Newton system at (chi, u, lam, t): Q [N][10][10], q [N][10], AB [N][4][10], c [N][4] -- what
+    `solve` hands to `_riccati` (and the GPU test hands to eepacc_nlp_riccati)."""
+    N = P.N
+    D = _linearize(P, chi, u, lam, nu, sigma)
+    r, Jr, AB = D["r"], D["Jr"], D["AB"]
+    c = D["f"] - chi[1:]
+    rg = r + t
+    Dg = lam / t
+    T = np.zeros((N, NY, NY))
+    T[:, np.arange(NX, NY), np.arange(NX, NY)] = 1.0
+    T[:, :NX, :] = AB
+    G = np.einsum("nri,nr,nrj->nij", Jr, Dg, Jr) + D["Gc"]
+    gam = np.einsum("nri,nr->ni", Jr, mu / t + Dg * rg)
+    cy = np.zeros((N, NY))
+    cy[:, :NX] = c
+    Q = D["Hl"] + np.einsum("nai,nab,nbj->nij", T, G, T)
+    q = D["gl"] + np.einsum("nai,na->ni", T, gam + np.einsum("nab,nb->na", G, cy))
+    return Q, q, AB, c
+
+
 def initial_point(P: NlpProblem):
     """Starting trajectory: a plain car-following rollout (the reference starts IPOPT from z0 = 0, RunOpt_NLP.m:348;
     an interior-point method that keeps the dynamics satisfied needs a drivable start instead).  Speed target =

@@ -146,3 +146,58 @@ def test_route_features_batch_and_determinism():
     o3 = ev.eval(stv[:, perm], X[:, :, perm], U[:, :, perm])
     assert np.array_equal(o3["J"].cpu().numpy(), J1[perm])
     assert np.array_equal(o3["ineq"].cpu().numpy(), r1[:, :, perm])
+
+
+def test_riccati_sweep_against_oracle():
+    """eepacc_nlp_riccati = oracle._riccati: (i) the Newton system of the interior-point solver at the car-following start
+    of the 60 s route and of the full route (first iteration: barrier 1, slacks off their rows), (ii) random
+    positive-definite stage data, (iii) an indefinite control block is reported, and accepted with a larger Levenberg term."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import riccati_batched
+    cases = []
+    for t_sim in (60.0, 435.0):
+        OPT, V, s_tv, _ = make_case(tree="ABO")
+        OPT["t_sim"] = t_sim
+        P = M.NlpProblem(OPT, V, s_tv)
+        chi, u = M.initial_point(P)
+        sigma, mu = 1e-5, 1.0
+        r = M._stage_values(P, chi, u, sigma)[2]
+        t = np.maximum(-r, 1e-2)
+        lam = mu / t
+        nu = np.zeros((P.N + 1, 4))
+        cases.append(M.assemble_newton(P, chi, u, lam, t, nu, mu, sigma))
+    rng = np.random.default_rng(2)
+    N = 50
+    A = rng.normal(0, 1, (N, 10, 10))
+    Qr = np.einsum("nij,nkj->nik", A, A) + 0.1 * np.eye(10)
+    ABr = rng.normal(0, 0.3, (N, 4, 10))
+    ABr[:, np.arange(4), np.arange(4)] += 0.9
+    cases.append((Qr, rng.normal(0, 1, (N, 10)), ABr, rng.normal(0, 0.1, (N, 4))))
+    for (Q, q, AB, c) in cases:
+        for reg in (0.0, 10.0):
+            ok, dchi, du, nu_ref, K, kf = M._riccati(Q, q, AB, c, reg)
+            assert ok
+            o = riccati_batched(Q[None], q[None], AB[None], c[None], np.array([reg]), reg_scale=M.REG_SCALE)
+            dchi_g, du_g, nu_g, st = (x.cpu().numpy() for x in o)
+            assert st[0] == 0
+            scale = lambda a: max(1.0, np.abs(a).max())
+            assert np.abs(du_g[0] - du).max() <= 1e-9 * scale(du)
+            assert np.abs(dchi_g[0] - dchi).max() <= 1e-9 * scale(dchi)
+            assert np.abs(nu_g[0] - nu_ref).max() <= 1e-9 * scale(nu_ref)
+    # batch: routes with different regularisation side by side give the single-route results
+    Q, q, AB, c = cases[0]
+    regs = np.array([0.0, 1.0, 100.0, 1e4])
+    o = riccati_batched(np.repeat(Q[None], 4, 0), np.repeat(q[None], 4, 0), np.repeat(AB[None], 4, 0), np.repeat(c[None], 4, 0), regs,
+                        reg_scale=M.REG_SCALE)
+    for i, reg in enumerate(regs):
+        ok, dchi, du, nu_ref, K, kf = M._riccati(Q, q, AB, c, float(reg))
+        assert ok and o[3][i].item() == 0
+        assert np.abs(o[1][i].cpu().numpy() - du).max() <= 1e-9 * max(1.0, np.abs(du).max())
+    # indefinite control block at one stage
+    Qb = Qr.copy()
+    Qb[20, 4, 4] = -50.0
+    ok = M._riccati(Qb, cases[2][1], ABr, cases[2][3], 0.0)[0]
+    assert not ok
+    o = riccati_batched(Qb[None], cases[2][1][None], ABr[None], cases[2][3][None], np.array([0.0]), reg_scale=np.ones(6))
+    assert o[3][0].item() == 1 + (N - 1 - 20)
+    o = riccati_batched(Qb[None], cases[2][1][None], ABr[None], cases[2][3][None], np.array([100.0]), reg_scale=np.ones(6))
+    assert o[3][0].item() == 0
