@@ -393,6 +393,258 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
     if (lane == 0) status[r] = bad;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Newton-system assembly of one interior-point iteration (include/eepacc_nlp.h: eepacc_nlp_newton).  One thread per
+// (route, interval).  Stage form: chi = (s, v, p, j) with p_k the acceleration at node k under the previous force and
+// theta substituted; second-order forward jets over (s_k, v_k, F_k) through the RK4 x 4 integrator (the power surface
+// through its scalar partials up to second order), rows with their sparse gradients and curvature, then
+// Q = H_L + T'(Jr' D Jr + curvature) T,  q = grad + T'(...)  with T = [AB; 0 I]  (the stage form of DESIGN.md section 3.8).
+// ---------------------------------------------------------------------------------------------------------------------
+struct H3 { double v, g[3], h[6]; };                      // h: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+__device__ __forceinline__ H3 h3c(double c) { H3 r; r.v = c; for (int i = 0; i < 3; ++i) r.g[i] = 0; for (int i = 0; i < 6; ++i) r.h[i] = 0; return r; }
+__device__ __forceinline__ H3 h3var(double x, int d) { H3 r = h3c(x); r.g[d] = 1.0; return r; }
+__device__ __forceinline__ H3 h3axpy(double c, const H3& a, const H3& b) {
+    H3 r; r.v = fma(c, a.v, b.v);
+    for (int i = 0; i < 3; ++i) r.g[i] = fma(c, a.g[i], b.g[i]);
+    for (int i = 0; i < 6; ++i) r.h[i] = fma(c, a.h[i], b.h[i]);
+    return r;
+}
+__device__ __forceinline__ H3 h3mul(const H3& a, const H3& b) {
+    H3 r; r.v = a.v * b.v;
+    for (int i = 0; i < 3; ++i) r.g[i] = a.v * b.g[i] + b.v * a.g[i];
+    const int I[6] = {0, 0, 0, 1, 1, 2}, Jx[6] = {0, 1, 2, 1, 2, 2};
+    for (int e = 0; e < 6; ++e) r.h[e] = a.v * b.h[e] + b.v * a.h[e] + a.g[I[e]] * b.g[Jx[e]] + a.g[Jx[e]] * b.g[I[e]];
+    return r;
+}
+__device__ __forceinline__ H3 h3fn(const H3& x, double f, double f1, double f2) {
+    H3 r; r.v = f;
+    for (int i = 0; i < 3; ++i) r.g[i] = f1 * x.g[i];
+    const int I[6] = {0, 0, 0, 1, 1, 2}, Jx[6] = {0, 1, 2, 1, 2, 2};
+    for (int e = 0; e < 6; ++e) r.h[e] = f1 * x.h[e] + f2 * x.g[I[e]] * x.g[Jx[e]];
+    return r;
+}
+// second-order partials of the power surface
+__device__ __forceinline__ void p_bat2(const double* b, double F, double r, double& PF, double& Pr, double& PFF, double& PFr, double& Prr) {
+    const double F2 = F * F, F3 = F2 * F, F4 = F2 * F2, r2 = r * r, r3 = r2 * r, r4 = r2 * r2;
+    PF = b[1] + 2.0 * b[3] * F + b[4] * r + 3.0 * b[6] * F2 + 2.0 * b[7] * F * r + b[8] * r2 + 4.0 * b[10] * F3 + 3.0 * b[11] * F2 * r
+       + 2.0 * b[12] * F * r2 + b[13] * r3 + 5.0 * b[15] * F4 + 4.0 * b[16] * F3 * r + 3.0 * b[17] * F2 * r2 + 2.0 * b[18] * F * r3 + b[19] * r4;
+    Pr = b[2] + b[4] * F + 2.0 * b[5] * r + b[7] * F2 + 2.0 * b[8] * F * r + 3.0 * b[9] * r2 + b[11] * F3 + 2.0 * b[12] * F2 * r
+       + 3.0 * b[13] * F * r2 + 4.0 * b[14] * r3 + b[16] * F4 + 2.0 * b[17] * F3 * r + 3.0 * b[18] * F2 * r2 + 4.0 * b[19] * F * r3 + 5.0 * b[20] * r4;
+    PFF = 2.0 * b[3] + 6.0 * b[6] * F + 2.0 * b[7] * r + 12.0 * b[10] * F2 + 6.0 * b[11] * F * r + 2.0 * b[12] * r2 + 20.0 * b[15] * F3
+        + 12.0 * b[16] * F2 * r + 6.0 * b[17] * F * r2 + 2.0 * b[18] * r3;
+    PFr = b[4] + 2.0 * b[7] * F + 2.0 * b[8] * r + 3.0 * b[11] * F2 + 4.0 * b[12] * F * r + 3.0 * b[13] * r2 + 4.0 * b[16] * F3
+        + 6.0 * b[17] * F2 * r + 6.0 * b[18] * F * r2 + 4.0 * b[19] * r3;
+    Prr = 2.0 * b[5] + 2.0 * b[8] * F + 6.0 * b[9] * r + 2.0 * b[12] * F2 + 6.0 * b[13] * F * r + 12.0 * b[14] * r2 + 2.0 * b[17] * F3
+        + 6.0 * b[18] * F2 * r + 12.0 * b[19] * F * r2 + 20.0 * b[20] * r3;
+}
+
+__global__ void __launch_bounds__(64)
+k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, double mu, double sigma, const double* __restrict__ s_tv,
+             const double* __restrict__ chi, const double* __restrict__ u, const double* __restrict__ lam, const double* __restrict__ tt,
+             const double* __restrict__ nu, double* __restrict__ Qo, double* __restrict__ qo, double* __restrict__ ABo,
+             double* __restrict__ co, double* __restrict__ ro) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)C.N * B) return;
+    const int rt = (int)(idx / C.N), k = (int)(idx % C.N);
+    const eepacc_vehicle& V = C.V;
+    const double* x0 = chi + ((size_t)rt * (C.N + 1) + k) * 4;
+    const double* x1 = x0 + 4;
+    const double* uk = u + ((size_t)rt * C.N + k) * 6;
+    const double* lm_ = lam + ((size_t)rt * C.N + k) * C.R;
+    const double* tk = tt + ((size_t)rt * C.N + k) * C.R;
+    const double* nu1 = nu + ((size_t)rt * (C.N + 1) + k + 1) * 4;
+    const double s0 = x0[0], v0 = x0[1], p0 = x0[2], j0 = x0[3];
+    const double Fm = uk[0], Fb = uk[1], xv = uk[2], xh = uk[3], xs = uk[4], xf = uk[5], F = Fm + Fb;
+    const double lmass = V.lambda * V.m, ilm = 1.0 / lmass, mg = V.m * V.g, kr = (30.0 / M_PI) * V.phi;
+    const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
+    double th0 = 0.0, dth0 = 0.0;
+    if (!C.flat) pwa(t_slope, s0, th0, dth0);
+    H3 th = h3c(th0); th.g[0] = dth0;
+    const H3 grav = h3axpy(V.c_r * mg, h3fn(th, cos(th0), -sin(th0), -cos(th0)), h3axpy(mg, h3fn(th, sin(th0), cos(th0), -sin(th0)), h3c(0.0)));
+    const H3 jF = h3var(F, 2);
+    // running cost: value, gradient (s, v, F, Fm), Hessian (4 x 4 packed: 00 01 02 03 11 12 13 22 23 33)
+    double qv = 0.0, qg[4] = {0, 0, 0, 0}, qh[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto f = [&](const H3& vv, double w, H3& a) {
+        a = h3axpy(ilm, h3axpy(-V.zeta_a, h3mul(vv, vv), h3axpy(-1.0, grav, jF)), h3c(0.0));
+        double P, PF, Pr, PFF, PFr, Prr, dummy1, dummy2;
+        p_bat(C.b, Fm, kr * vv.v, P, dummy1, dummy2);
+        p_bat2(C.b, Fm, kr * vv.v, PF, Pr, PFF, PFr, Prr);
+        const double W0 = C.W[0], W1 = C.W[1];
+        qv = fma(w, W0 * P + W1 * a.v * a.v, qv);
+        for (int d = 0; d < 3; ++d) qg[d] = fma(w, W0 * Pr * kr * vv.g[d] + 2.0 * W1 * a.v * a.g[d], qg[d]);
+        qg[3] = fma(w, W0 * PF, qg[3]);
+        const int I[6] = {0, 0, 0, 1, 1, 2}, Jx[6] = {0, 1, 2, 1, 2, 2}, Hq[6] = {0, 1, 2, 4, 5, 7};
+        for (int e = 0; e < 6; ++e)
+            qh[Hq[e]] = fma(w, W0 * (Prr * kr * kr * vv.g[I[e]] * vv.g[Jx[e]] + Pr * kr * vv.h[e])
+                               + 2.0 * W1 * (a.g[I[e]] * a.g[Jx[e]] + a.v * a.h[e]), qh[Hq[e]]);
+        qh[3] = fma(w, W0 * PFr * kr * vv.g[0], qh[3]);
+        qh[6] = fma(w, W0 * PFr * kr * vv.g[1], qh[6]);
+        qh[8] = fma(w, W0 * PFr * kr * vv.g[2], qh[8]);
+        qh[9] = fma(w, W0 * PFF, qh[9]);
+    };
+    const double DT = C.Ts / 4;
+    H3 v = h3var(v0, 1), ds = h3c(0.0);
+    for (int mstep = 0; mstep < 4; ++mstep) {
+        H3 a, asum, vsum;
+        f(v, DT / 6, a); asum = a; vsum = v;
+        const H3 v2 = h3axpy(DT / 2, a, v);
+        f(v2, DT / 3, a); asum = h3axpy(2.0, a, asum); vsum = h3axpy(2.0, v2, vsum);
+        const H3 v3 = h3axpy(DT / 2, a, v);
+        f(v3, DT / 3, a); asum = h3axpy(2.0, a, asum); vsum = h3axpy(2.0, v3, vsum);
+        const H3 v4 = h3axpy(DT, a, v);
+        f(v4, DT / 6, a); asum = h3axpy(1.0, a, asum); vsum = h3axpy(1.0, v4, vsum);
+        ds = h3axpy(DT / 6, vsum, ds);
+        v = h3axpy(DT / 6, asum, v);
+    }
+    H3 s1 = ds; s1.v += s0; s1.g[0] += 1.0;
+    double th1 = 0.0, dth1 = 0.0;
+    if (!C.flat) pwa(t_slope, s1.v, th1, dth1);
+    H3 thj = h3c(th1);
+    for (int i = 0; i < 3; ++i) thj.g[i] = dth1 * s1.g[i];
+    for (int i = 0; i < 6; ++i) thj.h[i] = dth1 * s1.h[i];
+    const H3 c1j = h3fn(thj, cos(th1), -sin(th1), -cos(th1)), s1j = h3fn(thj, sin(th1), cos(th1), -sin(th1));
+    const H3 p1 = h3axpy(ilm, h3axpy(-V.zeta_a, h3mul(v, v), h3axpy(-V.c_r * mg, c1j, h3axpy(-mg, s1j, jF))), h3c(0.0));
+
+    // ---- (chi_k, u_k) coordinates: 0 s, 1 v, 2 p, 3 j, 4 Fm, 5 Fb, 6 xi_v, 7 xi_h, 8 xi_s, 9 xi_f ----
+    double AB[4][10], gl[10], Q[10][10];
+    for (int i = 0; i < 10; ++i) { gl[i] = 0.0; for (int a2 = 0; a2 < 4; ++a2) AB[a2][i] = 0.0; for (int j2 = 0; j2 < 10; ++j2) Q[i][j2] = 0.0; }
+    auto put_g = [&](double* row, const H3& z, double w) { row[0] += w * z.g[0]; row[1] += w * z.g[1]; row[4] += w * z.g[2]; row[5] += w * z.g[2]; };
+    put_g(AB[0], s1, 1.0); put_g(AB[1], v, 1.0); put_g(AB[2], p1, 1.0); put_g(AB[3], p1, 1.0 / C.Ts);
+    AB[3][2] -= 1.0 / C.Ts;
+    const double cdef[4] = {s1.v - x1[0], v.v - x1[1], p1.v - x1[2], (p1.v - p0) / C.Ts - x1[3]};
+    const double* W = C.W;
+    gl[0] = sigma * qg[0]; gl[1] = sigma * qg[1]; gl[4] = sigma * (qg[2] + qg[3]); gl[5] = sigma * qg[2];
+    gl[3] = sigma * C.Ts * 2.0 * W[2] * j0;
+    gl[6] = sigma * C.Ts * W[3]; gl[7] = sigma * C.Ts * W[4] * (2.0 * xh + 1e2); gl[8] = sigma * C.Ts * W[5]; gl[9] = sigma * C.Ts * W[6];
+    // Lagrangian Hessian without the barrier terms
+    {
+        const int dirs3[3][2] = {{0, -1}, {1, -1}, {4, 5}};                  // s, v, F -> coordinates
+        const int I[6] = {0, 0, 0, 1, 1, 2}, Jx[6] = {0, 1, 2, 1, 2, 2}, Hq[6] = {0, 1, 2, 4, 5, 7};
+        const double wsv = nu1[0], wv = nu1[1], wp = nu1[2] + nu1[3] / C.Ts;
+        for (int e = 0; e < 6; ++e) {
+            const double val = sigma * qh[Hq[e]] + wsv * s1.h[e] + wv * v.h[e] + wp * p1.h[e];
+            for (int a2 = 0; a2 < 2; ++a2) for (int b2 = 0; b2 < 2; ++b2) {
+                const int ia = dirs3[I[e]][a2], ib = dirs3[Jx[e]][b2];
+                if (ia < 0 || ib < 0) continue;
+                Q[ia][ib] += val;
+                if (I[e] != Jx[e]) Q[ib][ia] += val;
+            }
+        }
+        // Fm direction of the cost: (s,Fm) (v,Fm) (F,Fm) (Fm,Fm)
+        Q[0][4] += sigma * qh[3]; Q[4][0] += sigma * qh[3];
+        Q[1][4] += sigma * qh[6]; Q[4][1] += sigma * qh[6];
+        Q[4][4] += 2.0 * sigma * qh[8]; Q[4][5] += sigma * qh[8]; Q[5][4] += sigma * qh[8];
+        Q[4][4] += sigma * qh[9];
+        Q[3][3] += sigma * C.Ts * 2.0 * W[2];
+        Q[7][7] += sigma * C.Ts * 2.0 * W[4];
+    }
+
+    // ---- rows in y = (chi_{k+1}, u_k): G = Jr' D Jr + lam * curvature, gam = Jr'(mu/t + D (r + t)) ----
+    double G[10][10], gam[10];
+    for (int i = 0; i < 10; ++i) { gam[i] = 0.0; for (int j2 = 0; j2 < 10; ++j2) G[i][j2] = 0.0; }
+    int n = 0;
+    double* rout = ro ? ro + ((size_t)rt * C.N + k) * C.R : nullptr;
+    auto row = [&](double rv, int cnt, const int* ix, const double* gv) {
+        const double tv = tk[n], lv = lm_[n], D = lv / tv, wgt = mu / tv + D * (rv + tv);
+        for (int a2 = 0; a2 < cnt; ++a2) {
+            gam[ix[a2]] += wgt * gv[a2];
+            for (int b2 = 0; b2 < cnt; ++b2) G[ix[a2]][ix[b2]] += D * gv[a2] * gv[b2];
+        }
+        if (rout) rout[n] = rv;
+        ++n;
+    };
+    auto curv = [&](int rowi, int a2, int b2, double val) {
+        const double c2 = lm_[rowi] * val;
+        G[a2][b2] += c2;
+        if (a2 != b2) G[b2][a2] += c2;
+    };
+    const double sN = x1[0], vN = x1[1], pN = x1[2], jN = x1[3];
+    double thN = 0.0, dthN = 0.0;
+    if (!C.flat) pwa(t_slope, sN, thN, dthN);
+    const double cN = cos(thN), snN = sin(thN);
+    double val, sl;
+    { const int ix[3] = {1, 4, 9}; const double g[3] = {-Fm, -vN, -1.0}; row(-(Fm * vN + V.P_m_max / V.eta_TF + xf), 3, ix, g); curv(n - 1, 1, 4, -1.0); }
+    { const int ix[3] = {1, 4, 9}; const double g[3] = {Fm, vN, -1.0}; row(Fm * vN - V.P_m_max * V.eta_TF - xf, 3, ix, g); curv(n - 1, 1, 4, 1.0); }
+    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {-1.0, -1.0, V.mu * mg * snN * dthN, -1.0}; row(-(F + V.mu * mg * cN + xf), 4, ix, g); }
+    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {1.0, 1.0, V.mu * mg * snN * dthN, -1.0}; row(F - V.mu * mg * cN - xf, 4, ix, g); }
+    const double kF = V.L / (V.mu * V.m), kz = V.h_g * V.zeta_a / V.m;
+    const double rear = V.h_g * V.lambda * pN + kz * vN * vN + V.g * (V.L_f * cN + V.h_g * snN);
+    const double drear = V.g * (-V.L_f * snN + V.h_g * cN) * dthN;
+    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {-kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; row(-(kF * Fm + rear + xf), 5, ix, g); curv(n - 1, 1, 1, -2.0 * kz); }
+    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; row(kF * Fm - rear - xf, 5, ix, g); curv(n - 1, 1, 1, -2.0 * kz); }
+    const double iso_v[4] = {0.0, 5.0, 20.0, 25.0};
+    const double iso_amin[4] = {-4.0, -4.0, -2.0, -2.0}, iso_amax[4] = {5.0, 5.0, 3.5, 3.5}, iso_j[4] = {5.0, 5.0, 2.5, 2.5};
+    pwa(Tab{iso_v, iso_amin, 4}, vN, val, sl);
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {-1.0, sl, -1.0}; row(-(pN - val + xf), 3, ix, g); }
+    pwa(Tab{iso_v, iso_amax, 4}, vN, val, sl);
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; row(pN - val - xf, 3, ix, g); }
+    pwa(Tab{iso_v, iso_j, 4}, vN, val, sl);
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {-1.0, -sl, -1.0}; row(-(jN + val + xf), 3, ix, g); }
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; row(jN - val - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_vlim, blob + C.o_vlim + C.n_vlim, C.n_vlim}, sN, val, sl);
+    { const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_curv, blob + C.o_curv + C.n_curv, C.n_curv}, sN, val, sl);
+    { const double ac = fmax(fabs(val), 1e-300);
+      const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * (val > 0 ? 1.0 : (val < 0 ? -1.0 : 0.0)) * sl, -1.0};
+      row(vN - C.alpha * pow(ac, -1.0 / 3.0) - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_stop, blob + C.o_stop + C.n_stop, C.n_stop}, sN, val, sl);
+    { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - xs, 3, ix, g); }
+    for (int tl = 0; tl < C.n_tl; ++tl) {
+        pwa(Tab{blob + C.o_tls + 3 * tl, C.tl_v, 3}, sN, val, sl);
+        const double tst = blob[C.o_tlstate + (size_t)tl * C.N + k];
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - tst - xs, 3, ix, g); }
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {-1.0, -sl, -1.0}; row(-(vN + val + 1e3 - 10.0 - tst + xs), 3, ix, g); }
+    }
+    pwa(Tab{blob + C.o_vinc, blob + C.o_vinc + C.n_vinc, C.n_vinc}, sN, val, sl);
+    { const int ix[3] = {1, 0, 6}; const double g[3] = {-1.0, sl, -1.0}; row(-(vN - val + xv), 3, ix, g); }
+    const double stv = s_tv[(size_t)rt * C.N + k];
+    { const int ix[1] = {0}; const double g[1] = {1.0}; row(sN - (stv - C.h_min), 1, ix, g); }
+    { const int ix[3] = {0, 1, 8}; const double g[3] = {1.0, C.tau_min, -1.0}; row(sN + C.tau_min * vN - xs - stv, 3, ix, g); }
+    const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
+    { const int ix[3] = {0, 1, 7}; const double g[3] = {1.0, T_hwp + 2.0 * G_hwp * vN, -1.0}; row(sN + vN * T_hwp + vN * vN * G_hwp - xh - (stv - A_hwp), 3, ix, g); curv(n - 1, 1, 1, 2.0 * G_hwp); }
+    { const int ix[1] = {4}; const double g[1] = {-1.0}; row(C.Fm_min - Fm, 1, ix, g); }
+    { const int ix[1] = {4}; const double g[1] = {1.0}; row(Fm - C.Fm_max, 1, ix, g); }
+    { const int ix[1] = {5}; const double g[1] = {1.0}; row(Fb, 1, ix, g); }
+    for (int sidx = 6; sidx < 10; ++sidx) { const int ix[1] = {sidx}; const double g[1] = {-1.0}; row(-uk[sidx - 4], 1, ix, g); }
+    { const int ix[1] = {0}; const double g[1] = {-1.0}; row(-sN, 1, ix, g); }
+    { const int ix[1] = {1}; const double g[1] = {-1.0}; row(-vN, 1, ix, g); }
+    { const int ix[1] = {1}; const double g[1] = {1.0}; row(vN - V.v_max, 1, ix, g); }
+    if (C.has_goal) { const int ix[1] = {0}; const double g[1] = {1.0}; row(sN - C.s_goal, 1, ix, g); }
+
+    // ---- Q = H_L + T' G T,  q = gl + T'(gam + G (c, 0)),  T = [AB; 0 I] ----
+    double GA[4][10], gx[4];
+    for (int a2 = 0; a2 < 4; ++a2) {
+        gx[a2] = gam[a2];
+        for (int b2 = 0; b2 < 4; ++b2) gx[a2] += G[a2][b2] * cdef[b2];
+        for (int i = 0; i < 10; ++i) {
+            double acc = 0.0;
+            for (int b2 = 0; b2 < 4; ++b2) acc += G[a2][b2] * AB[b2][i];
+            GA[a2][i] = acc;
+        }
+    }
+    double* Qout = Qo + ((size_t)rt * C.N + k) * 100;
+    double* qout = qo + ((size_t)rt * C.N + k) * 10;
+    for (int i = 0; i < 10; ++i) {
+        double qi = gl[i];
+        for (int a2 = 0; a2 < 4; ++a2) qi += AB[a2][i] * gx[a2];
+        if (i >= 4) { qi += gam[i]; for (int b2 = 0; b2 < 4; ++b2) qi += G[i][b2] * cdef[b2]; }
+        qout[i] = qi;
+        for (int j2 = 0; j2 < 10; ++j2) {
+            double acc = Q[i][j2];
+            for (int a2 = 0; a2 < 4; ++a2) acc += AB[a2][i] * GA[a2][j2];
+            if (j2 >= 4) for (int a2 = 0; a2 < 4; ++a2) acc += AB[a2][i] * G[a2][j2];
+            if (i >= 4) for (int a2 = 0; a2 < 4; ++a2) acc += G[i][a2] * AB[a2][j2];
+            if (i >= 4 && j2 >= 4) acc += G[i][j2];
+            Qout[i * 10 + j2] = acc;
+        }
+    }
+    double* ABout = ABo + ((size_t)rt * C.N + k) * 40;
+    for (int a2 = 0; a2 < 4; ++a2) for (int i = 0; i < 10; ++i) ABout[a2 * 10 + i] = AB[a2][i];
+    double* cout = co + ((size_t)rt * C.N + k) * 4;
+    for (int a2 = 0; a2 < 4; ++a2) cout[a2] = cdef[a2];
+}
+
 }  // namespace
 
 struct eepacc_nlp_handle {
@@ -523,6 +775,19 @@ extern "C" int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev,
     for (int i = 0; i < 6; ++i) sc.s[i] = reg_scale[i];
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, Q_dev, q_dev, AB_dev, c_dev, reg_dev, sc,
                        dchi_dev, du_dev, nu_dev, work_dev, status_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, double mu, double sigma, const double* s_tv_dev, const double* chi_dev,
+                                 const double* u_dev, const double* lam_dev, const double* t_dev, const double* nu_dev,
+                                 double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, void* stream) {
+    if (!h || B < 1 || !s_tv_dev || !chi_dev || !u_dev || !lam_dev || !t_dev || !nu_dev || !Q_dev || !q_dev || !AB_dev || !c_dev)
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_newton: null argument or B < 1");
+    NLPCHK(hipSetDevice(h->device));
+    const size_t units = (size_t)h->C.N * B;
+    hipLaunchKernelGGL(k_nlp_newton, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, mu, sigma,
+                       s_tv_dev, chi_dev, u_dev, lam_dev, t_dev, nu_dev, Q_dev, q_dev, AB_dev, c_dev, rows_dev);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }

@@ -194,6 +194,7 @@ def _bind(lib):
     lib.eepacc_nlp_destroy.restype = None
     lib.eepacc_nlp_eval.argtypes = [vp, C.c_int] + [vp] * 9
     lib.eepacc_nlp_synchronize.argtypes = [vp, vp]
+    lib.eepacc_nlp_newton.argtypes = [vp, C.c_int, C.c_double, C.c_double] + [vp] * 12
     lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp]
     return lib
 
@@ -291,6 +292,33 @@ class NlpEvaluator:
         if rc != 0:
             raise self._err("eepacc_nlp_eval failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
         return o
+
+    def newton(self, s_tv, chi, u, lam, t, nu, mu: float, sigma: float):
+        """eepacc_nlp_newton: route-major chi [B][N+1][4], u [B][N][6], lam / t [B][N][R], nu [B][N+1][4], s_tv [B][N].
+        Returns (Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4], rows [B][N][R]) as CUDA tensors."""
+        import torch
+        dev = torch.device("cuda", self.device)
+
+        def d(x):
+            tt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+            return tt.to(device=dev, dtype=torch.float64).contiguous()
+        s_tv, chi, u, lam, t, nu = (d(x) for x in (s_tv, chi, u, lam, t, nu))
+        N, R = self.N, self.R
+        B = int(chi.shape[0])
+        assert chi.shape == (B, N + 1, 4) and u.shape == (B, N, 6) and lam.shape == (B, N, R) and t.shape == (B, N, R)
+        assert nu.shape == (B, N + 1, 4) and s_tv.shape == (B, N)
+        Q = torch.empty((B, N, 10, 10), dtype=torch.float64, device=dev)
+        q = torch.empty((B, N, 10), dtype=torch.float64, device=dev)
+        AB = torch.empty((B, N, 4, 10), dtype=torch.float64, device=dev)
+        c = torch.empty((B, N, 4), dtype=torch.float64, device=dev)
+        rows = torch.empty((B, N, R), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.eepacc_nlp_newton(self.h, B, float(mu), float(sigma), s_tv.data_ptr(), chi.data_ptr(), u.data_ptr(),
+                                        lam.data_ptr(), t.data_ptr(), nu.data_ptr(), Q.data_ptr(), q.data_ptr(), AB.data_ptr(),
+                                        c.data_ptr(), rows.data_ptr(), stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_newton failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return Q, q, AB, c, rows
 
     def synchronize(self):
         import torch

@@ -84,6 +84,17 @@ int eepacc_nlp_eval(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const d
                     void* stream);
 int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream);
 
+/* Newton-system assembly of one interior-point iteration in stage form (chi = (s, v, p, j): p_k is the acceleration at
+ * node k under the previous force -- the bracket of the jerk row, RunOpt_NLP.m:371-375 --, theta substituted): for every
+ * (route, interval) the exact Lagrangian Hessian (second-order sensitivities of the RK4 x 4 integrator and of the
+ * running cost, row curvature), the barrier terms of all rows and the linearised dynamics, condensed to the blocks
+ * eepacc_nlp_riccati takes.  Route-major arrays: chi [B][N+1][4], u [B][N][6], lam / t [B][N][R] (multipliers and slacks of
+ * the rows, R = eepacc_nlp_rows), nu [B][N+1][4] (costates), s_tv [B][N]; mu = barrier parameter, sigma = objective scale.
+ * Outputs Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4] and, if not NULL, the row values [B][N][R]. */
+int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, double mu, double sigma, const double* s_tv_dev, const double* chi_dev,
+                      const double* u_dev, const double* lam_dev, const double* t_dev, const double* nu_dev,
+                      double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, void* stream);
+
 /* Stage-wise factorisation of one Newton system per route: the linear solve inside every interior-point iteration
  * (what IPOPT hands to MUMPS in the reference, RunOpt_NLP.m:505-510), exploiting that the problem is an optimal-control
  * problem: with chi = (s, v, p, j), u = the six controls / slacks and w_k = (chi_k, u_k) it solves

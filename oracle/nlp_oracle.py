@@ -298,6 +298,7 @@ class NlpOptions:
         self.reg_first = 1e-4
         self.reg_max = 1e8
         self.verbose = False
+        self.primal = False          # True: rows that hold use lam = mu / t (Newton on the primal barrier function)
         self.__dict__.update(kw)
 
 
@@ -619,6 +620,8 @@ def solve(P: NlpProblem, opt: NlpOptions | None = None, start=None):
     T = np.zeros((N, NY, NY))
     T[:, np.arange(NX, NY), np.arange(NX, NY)] = 1.0
     for it in range(o.max_iter):
+        if o.primal:
+            lam = np.where(r + t > 1e-9 * (1.0 + t), lam, mu / t)     # rows that hold: multiplier of the primal barrier
         D = _linearize(P, chi, u, lam, nu, sigma)
         r, Jr, AB = D["r"], D["Jr"], D["AB"]
         c = D["f"] - chi[1:]

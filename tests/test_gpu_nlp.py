@@ -201,3 +201,52 @@ def test_riccati_sweep_against_oracle():
     assert o[3][0].item() == 1 + (N - 1 - 20)
     o = riccati_batched(Qb[None], cases[2][1][None], ABr[None], cases[2][3][None], np.array([100.0]), reg_scale=np.ones(6))
     assert o[3][0].item() == 0
+
+
+@pytest.mark.parametrize("features", [False, True])
+def test_newton_assembly_and_step_against_oracle(features):
+    """eepacc_nlp_newton = oracle.assemble_newton (exact Lagrangian Hessian, barrier terms, linearised dynamics, defects)
+    at a perturbed interior point with random multipliers and costates, and newton + riccati = the oracle's Newton step.
+    `features`: a route with a stop, a traffic light, a curve, a slope and a finite s_goal (all lookups, theta != 0)."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpEvaluator, riccati_batched
+    from eepacc_mpc_casadi_matlab_amd.settings import GenerateUseCase
+    if features:
+        OPT, V, s_tv, _ = make_case(tree="ABO", stopLoc=np.array([400.0]), TLLoc=np.array([[800.0, 5.0, 20.0, 30.0]]),
+                                    curves=np.array([[0.02, 1500.0, 1600.0]]), slopes=np.array([[8.0, 300.0, 700.0]]),
+                                    s_goal=5000.0)
+        OPT = GenerateUseCase(OPT)
+    else:
+        OPT, V, s_tv, _ = make_case(tree="ABO")
+    OPT["t_sim"] = 120.0
+    P = M.NlpProblem(OPT, V, s_tv)
+    ev = NlpEvaluator(OPT, V)
+    N, R = P.N, P.n_rows
+    assert ev.R == R
+    rng = np.random.default_rng(7)
+    chi, u = M.initial_point(P)
+    chi[1:, 0] += rng.normal(0, 0.5, N)
+    chi[1:, 1] = np.abs(chi[1:, 1] + rng.normal(0, 0.2, N)) + 0.05
+    chi[1:, 2] += rng.normal(0, 0.05, N)
+    chi[1:, 3] += rng.normal(0, 0.05, N)
+    u[:, 0] += rng.normal(0, 50.0, N)
+    sigma, mu = 1e-5, 0.1
+    r = M._stage_values(P, chi, u, sigma)[2]
+    t = np.maximum(-r, 1e-2) * rng.uniform(0.8, 1.2, r.shape)
+    lam = mu / t * rng.uniform(0.5, 2.0, r.shape)
+    nu = rng.normal(0, 1.0, (N + 1, 4))
+    Q, q, AB, c = M.assemble_newton(P, chi, u, lam, t, nu, mu, sigma)
+    out = ev.newton(P.s_tv[None], chi[None], u[None], lam[None], t[None], nu[None], mu, sigma)
+    Qg, qg, ABg, cg, rg = (x.cpu().numpy()[0] for x in out)
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert np.abs(rg - r).max() < 1e-9 * 1e2
+    assert rel(ABg, AB) < 1e-10 and np.abs(cg - c).max() < 1e-10
+    assert rel(qg, q) < 1e-10, rel(qg, q)
+    assert rel(Qg, Q) < 1e-10, rel(Qg, Q)
+    assert np.abs(Qg - np.swapaxes(Qg, 1, 2)).max() <= 1e-12 * np.abs(Qg).max()
+    # the Newton step of the two GPU operators = the oracle's
+    ok, dchi, du, nu_new, K, kf = M._riccati(Q, q, AB, c, 10.0)
+    assert ok
+    o = riccati_batched(out[0], out[1], out[2], out[3], np.array([10.0]), reg_scale=M.REG_SCALE)
+    assert o[3][0].item() == 0
+    assert np.abs(o[1][0].cpu().numpy() - du).max() <= 1e-7 * max(1.0, np.abs(du).max())
+    assert np.abs(o[0][0].cpu().numpy() - dchi).max() <= 1e-7 * max(1.0, np.abs(dchi).max())
