@@ -235,10 +235,11 @@ struct RicScale { double s[RU]; };
 __global__ void __launch_bounds__(64)
 k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict__ qg, const double* __restrict__ ABg,
           const double* __restrict__ cg, const double* __restrict__ regg, const RicScale sc, double* __restrict__ dchi,
-          double* __restrict__ du, double* __restrict__ nu, double* __restrict__ work, int32_t* __restrict__ status) {
+          double* __restrict__ du, double* __restrict__ nu, double* __restrict__ work, int32_t* __restrict__ status,
+          double* __restrict__ gnorm, const double* __restrict__ qlam) {
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B) return;
-    __shared__ double M[RY][RY], m[RY], AB[RX][RY], W[RX][RY], P[RX][RX], pv[RX], pc[RX], cvec[RX], Kk[RU][RX + 1];
+    __shared__ double M[RY][RY], m[RY], AB[RX][RY], W[RX][RY], P[RX][RX], pv[RX], pc[RX], cvec[RX], Kk[RU][RX + 1], ql[RY], wad[RX];
     const double reg = regg[r];
     const double* Qr = Qg + (size_t)r * N * 100;
     const double* qr = qg + (size_t)r * N * 10;
@@ -246,8 +247,10 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
     const double* cr = cg + (size_t)r * N * 4;
     double* wr = work + (size_t)r * N * 50;
     if (lane < 16) P[lane >> 2][lane & 3] = 0.0;
-    if (lane < 4) pv[lane] = 0.0;
+    if (lane < 4) { pv[lane] = 0.0; wad[lane] = 0.0; }
+    const double* qlr = qlam ? qlam + (size_t)r * N * 10 : nullptr;
     int bad = 0;
+    double gmax = 0.0;                                     // max |reduced gradient| over the stages (lanes 0..5: one control each)
     __syncthreads();
     // stage data travel global -> registers -> LDS one stage ahead of the arithmetic (the sweep is a chain of dependent
     // stages: a load issued at the top of its own stage would put the whole memory latency on the critical path)
@@ -258,6 +261,7 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
         if (lane < 40) pre2 = ABr[(size_t)k * 40 + lane];
         else if (lane < 50) pre2 = qr[(size_t)k * 10 + lane - 40];
         else if (lane < 54) pre2 = cr[(size_t)k * 4 + lane - 50];
+        else if (qlr) pre2 = qlr[(size_t)k * 10 + lane - 54];
     };
     prefetch(N - 1);
     for (int k = N - 1; k >= 0; --k) {
@@ -266,8 +270,15 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
         if (lane < 40) AB[lane / 10][lane % 10] = pre2;
         else if (lane < 50) m[lane - 40] = pre2;
         else if (lane < 54) cvec[lane - 50] = pre2;
+        else ql[lane - 54] = pre2;
         __syncthreads();
         if (k > 0) prefetch(k - 1);
+        // dual residual with the current multipliers: adjoint w of the dynamics, reduced gradient per control
+        double wn = 0.0;
+        if (qlr) {
+            if (lane < RU) gmax = fmax(gmax, fabs(ql[RX + lane] + AB[0][RX + lane] * wad[0] + AB[1][RX + lane] * wad[1] + AB[2][RX + lane] * wad[2] + AB[3][RX + lane] * wad[3]));
+            else if (lane >= 8 && lane < 12) { const int x2 = lane - 8; wn = ql[x2] + AB[0][x2] * wad[0] + AB[1][x2] * wad[1] + AB[2][x2] * wad[2] + AB[3][x2] * wad[3]; }
+        }
         if (lane < 40) {                                   // W = P AB
             const int x = lane / 10, j = lane % 10;
             W[x][j] = P[x][0] * AB[0][j] + P[x][1] * AB[1][j] + P[x][2] * AB[2][j] + P[x][3] * AB[3][j];
@@ -284,6 +295,8 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
         }
         if (lane < 10) m[lane] += AB[0][lane] * pc[0] + AB[1][lane] * pc[1] + AB[2][lane] * pc[2] + AB[3][lane] * pc[3];
         __syncthreads();
+        if (!qlr && lane < RU) gmax = fmax(gmax, fabs(m[RX + lane]));
+        if (qlr && lane >= 8 && lane < 12) wad[lane - 8] = wn;
         // Cholesky of the control block, redundantly per lane; per-pivot relative test
         double L[RU][RU], invd[RU];
         bool ok = true;
@@ -391,8 +404,79 @@ k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict_
         __syncthreads();
     }
     if (lane == 0) status[r] = bad;
+    if (gnorm) {
+        __shared__ double gm[RU];
+        if (lane < RU) gm[lane] = gmax;
+        __syncthreads();
+        if (lane == 0) gnorm[r] = fmax(fmax(fmax(gm[0], gm[1]), fmax(gm[2], gm[3])), fmax(gm[4], gm[5]));
+    }
 }
 
+
+
+// Every inequality row of one interval in y = (chi_{k+1}, u_k) coordinates (0 s, 1 v, 2 p, 3 j, 4 Fm, 5 Fb, 6..9 slacks),
+// orientation value <= 0, in the order of RunOpt_NLP.m:378-501 followed by the bounds: row(value, count, indices,
+// gradient entries) returns the row's number, curv(row, a, b, value) reports a second-derivative entry.
+template <class RowF, class CurvF>
+__device__ __forceinline__ void nlp_rows(const NlpDev& C, const double* __restrict__ blob, int k, const double* x1, const double* uk,
+                                         double stv, RowF row, CurvF curv) {
+    const eepacc_vehicle& V = C.V;
+    const double mg = V.m * V.g;
+    const double Fm = uk[0], Fb = uk[1], xv = uk[2], xh = uk[3], xs = uk[4], xf = uk[5], F = Fm + Fb;
+    const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
+    const double sN = x1[0], vN = x1[1], pN = x1[2], jN = x1[3];
+    double thN = 0.0, dthN = 0.0;
+    if (!C.flat) pwa(t_slope, sN, thN, dthN);
+    const double cN = cos(thN), snN = sin(thN);
+    double val, sl;
+    { const int ix[3] = {1, 4, 9}; const double g[3] = {-Fm, -vN, -1.0}; const int n_last = row(-(Fm * vN + V.P_m_max / V.eta_TF + xf), 3, ix, g); curv(n_last, 1, 4, -1.0); }
+    { const int ix[3] = {1, 4, 9}; const double g[3] = {Fm, vN, -1.0}; const int n_last = row(Fm * vN - V.P_m_max * V.eta_TF - xf, 3, ix, g); curv(n_last, 1, 4, 1.0); }
+    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {-1.0, -1.0, V.mu * mg * snN * dthN, -1.0}; const int n_last = row(-(F + V.mu * mg * cN + xf), 4, ix, g); }
+    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {1.0, 1.0, V.mu * mg * snN * dthN, -1.0}; const int n_last = row(F - V.mu * mg * cN - xf, 4, ix, g); }
+    const double kF = V.L / (V.mu * V.m), kz = V.h_g * V.zeta_a / V.m;
+    const double rear = V.h_g * V.lambda * pN + kz * vN * vN + V.g * (V.L_f * cN + V.h_g * snN);
+    const double drear = V.g * (-V.L_f * snN + V.h_g * cN) * dthN;
+    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {-kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; const int n_last = row(-(kF * Fm + rear + xf), 5, ix, g); curv(n_last, 1, 1, -2.0 * kz); }
+    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; const int n_last = row(kF * Fm - rear - xf, 5, ix, g); curv(n_last, 1, 1, -2.0 * kz); }
+    const double iso_v[4] = {0.0, 5.0, 20.0, 25.0};
+    const double iso_amin[4] = {-4.0, -4.0, -2.0, -2.0}, iso_amax[4] = {5.0, 5.0, 3.5, 3.5}, iso_j[4] = {5.0, 5.0, 2.5, 2.5};
+    pwa(Tab{iso_v, iso_amin, 4}, vN, val, sl);
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(pN - val + xf), 3, ix, g); }
+    pwa(Tab{iso_v, iso_amax, 4}, vN, val, sl);
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(pN - val - xf, 3, ix, g); }
+    pwa(Tab{iso_v, iso_j, 4}, vN, val, sl);
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(jN + val + xf), 3, ix, g); }
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(jN - val - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_vlim, blob + C.o_vlim + C.n_vlim, C.n_vlim}, sN, val, sl);
+    { const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_curv, blob + C.o_curv + C.n_curv, C.n_curv}, sN, val, sl);
+    { const double ac = fmax(fabs(val), 1e-300);
+      const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * (val > 0 ? 1.0 : (val < 0 ? -1.0 : 0.0)) * sl, -1.0};
+      (void)row(vN - C.alpha * pow(ac, -1.0 / 3.0) - xf, 3, ix, g); }
+    pwa(Tab{blob + C.o_stop, blob + C.o_stop + C.n_stop, C.n_stop}, sN, val, sl);
+    { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xs, 3, ix, g); }
+    for (int tl = 0; tl < C.n_tl; ++tl) {
+        pwa(Tab{blob + C.o_tls + 3 * tl, C.tl_v, 3}, sN, val, sl);
+        const double tst = blob[C.o_tlstate + (size_t)tl * C.N + k];
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - tst - xs, 3, ix, g); }
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(vN + val + 1e3 - 10.0 - tst + xs), 3, ix, g); }
+    }
+    pwa(Tab{blob + C.o_vinc, blob + C.o_vinc + C.n_vinc, C.n_vinc}, sN, val, sl);
+    { const int ix[3] = {1, 0, 6}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(vN - val + xv), 3, ix, g); }
+    { const int ix[1] = {0}; const double g[1] = {1.0}; const int n_last = row(sN - (stv - C.h_min), 1, ix, g); }
+    { const int ix[3] = {0, 1, 8}; const double g[3] = {1.0, C.tau_min, -1.0}; const int n_last = row(sN + C.tau_min * vN - xs - stv, 3, ix, g); }
+    const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
+    { const int ix[3] = {0, 1, 7}; const double g[3] = {1.0, T_hwp + 2.0 * G_hwp * vN, -1.0}; const int n_last = row(sN + vN * T_hwp + vN * vN * G_hwp - xh - (stv - A_hwp), 3, ix, g); curv(n_last, 1, 1, 2.0 * G_hwp); }
+    { const int ix[1] = {4}; const double g[1] = {-1.0}; const int n_last = row(C.Fm_min - Fm, 1, ix, g); }
+    { const int ix[1] = {4}; const double g[1] = {1.0}; const int n_last = row(Fm - C.Fm_max, 1, ix, g); }
+    { const int ix[1] = {5}; const double g[1] = {1.0}; const int n_last = row(Fb, 1, ix, g); }
+    for (int sidx = 6; sidx < 10; ++sidx) { const int ix[1] = {sidx}; const double g[1] = {-1.0}; const int n_last = row(-uk[sidx - 4], 1, ix, g); }
+    { const int ix[1] = {0}; const double g[1] = {-1.0}; const int n_last = row(-sN, 1, ix, g); }
+    { const int ix[1] = {1}; const double g[1] = {-1.0}; const int n_last = row(-vN, 1, ix, g); }
+    { const int ix[1] = {1}; const double g[1] = {1.0}; const int n_last = row(vN - V.v_max, 1, ix, g); }
+    if (C.has_goal) { const int ix[1] = {0}; const double g[1] = {1.0}; const int n_last = row(sN - C.s_goal, 1, ix, g); }
+
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Newton-system assembly of one interior-point iteration (include/eepacc_nlp.h: eepacc_nlp_newton).  One thread per
@@ -440,14 +524,15 @@ __device__ __forceinline__ void p_bat2(const double* b, double F, double r, doub
 }
 
 __global__ void __launch_bounds__(64)
-k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, double mu, double sigma, const double* __restrict__ s_tv,
+k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ mu_arr, double sigma, const double* __restrict__ s_tv,
              const double* __restrict__ chi, const double* __restrict__ u, const double* __restrict__ lam, const double* __restrict__ tt,
              const double* __restrict__ nu, double* __restrict__ Qo, double* __restrict__ qo, double* __restrict__ ABo,
-             double* __restrict__ co, double* __restrict__ ro) {
+             double* __restrict__ co, double* __restrict__ ro, double* __restrict__ qlo) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)C.N * B) return;
     const int rt = (int)(idx / C.N), k = (int)(idx % C.N);
     const eepacc_vehicle& V = C.V;
+    const double mu = mu_arr[rt];
     const double* x0 = chi + ((size_t)rt * (C.N + 1) + k) * 4;
     const double* x1 = x0 + 4;
     const double* uk = u + ((size_t)rt * C.N + k) * 6;
@@ -541,76 +626,26 @@ k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, double mu, 
     }
 
     // ---- rows in y = (chi_{k+1}, u_k): G = Jr' D Jr + lam * curvature, gam = Jr'(mu/t + D (r + t)) ----
-    double G[10][10], gam[10];
-    for (int i = 0; i < 10; ++i) { gam[i] = 0.0; for (int j2 = 0; j2 < 10; ++j2) G[i][j2] = 0.0; }
+    double G[10][10], gam[10], gaml[10];
+    for (int i = 0; i < 10; ++i) { gam[i] = 0.0; gaml[i] = 0.0; for (int j2 = 0; j2 < 10; ++j2) G[i][j2] = 0.0; }
     int n = 0;
     double* rout = ro ? ro + ((size_t)rt * C.N + k) * C.R : nullptr;
     auto row = [&](double rv, int cnt, const int* ix, const double* gv) {
         const double tv = tk[n], lv = lm_[n], D = lv / tv, wgt = mu / tv + D * (rv + tv);
         for (int a2 = 0; a2 < cnt; ++a2) {
             gam[ix[a2]] += wgt * gv[a2];
+            gaml[ix[a2]] += lv * gv[a2];
             for (int b2 = 0; b2 < cnt; ++b2) G[ix[a2]][ix[b2]] += D * gv[a2] * gv[b2];
         }
         if (rout) rout[n] = rv;
-        ++n;
+        return n++;
     };
     auto curv = [&](int rowi, int a2, int b2, double val) {
         const double c2 = lm_[rowi] * val;
         G[a2][b2] += c2;
         if (a2 != b2) G[b2][a2] += c2;
     };
-    const double sN = x1[0], vN = x1[1], pN = x1[2], jN = x1[3];
-    double thN = 0.0, dthN = 0.0;
-    if (!C.flat) pwa(t_slope, sN, thN, dthN);
-    const double cN = cos(thN), snN = sin(thN);
-    double val, sl;
-    { const int ix[3] = {1, 4, 9}; const double g[3] = {-Fm, -vN, -1.0}; row(-(Fm * vN + V.P_m_max / V.eta_TF + xf), 3, ix, g); curv(n - 1, 1, 4, -1.0); }
-    { const int ix[3] = {1, 4, 9}; const double g[3] = {Fm, vN, -1.0}; row(Fm * vN - V.P_m_max * V.eta_TF - xf, 3, ix, g); curv(n - 1, 1, 4, 1.0); }
-    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {-1.0, -1.0, V.mu * mg * snN * dthN, -1.0}; row(-(F + V.mu * mg * cN + xf), 4, ix, g); }
-    { const int ix[4] = {4, 5, 0, 9}; const double g[4] = {1.0, 1.0, V.mu * mg * snN * dthN, -1.0}; row(F - V.mu * mg * cN - xf, 4, ix, g); }
-    const double kF = V.L / (V.mu * V.m), kz = V.h_g * V.zeta_a / V.m;
-    const double rear = V.h_g * V.lambda * pN + kz * vN * vN + V.g * (V.L_f * cN + V.h_g * snN);
-    const double drear = V.g * (-V.L_f * snN + V.h_g * cN) * dthN;
-    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {-kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; row(-(kF * Fm + rear + xf), 5, ix, g); curv(n - 1, 1, 1, -2.0 * kz); }
-    { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; row(kF * Fm - rear - xf, 5, ix, g); curv(n - 1, 1, 1, -2.0 * kz); }
-    const double iso_v[4] = {0.0, 5.0, 20.0, 25.0};
-    const double iso_amin[4] = {-4.0, -4.0, -2.0, -2.0}, iso_amax[4] = {5.0, 5.0, 3.5, 3.5}, iso_j[4] = {5.0, 5.0, 2.5, 2.5};
-    pwa(Tab{iso_v, iso_amin, 4}, vN, val, sl);
-    { const int ix[3] = {2, 1, 9}; const double g[3] = {-1.0, sl, -1.0}; row(-(pN - val + xf), 3, ix, g); }
-    pwa(Tab{iso_v, iso_amax, 4}, vN, val, sl);
-    { const int ix[3] = {2, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; row(pN - val - xf, 3, ix, g); }
-    pwa(Tab{iso_v, iso_j, 4}, vN, val, sl);
-    { const int ix[3] = {3, 1, 9}; const double g[3] = {-1.0, -sl, -1.0}; row(-(jN + val + xf), 3, ix, g); }
-    { const int ix[3] = {3, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; row(jN - val - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_vlim, blob + C.o_vlim + C.n_vlim, C.n_vlim}, sN, val, sl);
-    { const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_curv, blob + C.o_curv + C.n_curv, C.n_curv}, sN, val, sl);
-    { const double ac = fmax(fabs(val), 1e-300);
-      const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * (val > 0 ? 1.0 : (val < 0 ? -1.0 : 0.0)) * sl, -1.0};
-      row(vN - C.alpha * pow(ac, -1.0 / 3.0) - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_stop, blob + C.o_stop + C.n_stop, C.n_stop}, sN, val, sl);
-    { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - xs, 3, ix, g); }
-    for (int tl = 0; tl < C.n_tl; ++tl) {
-        pwa(Tab{blob + C.o_tls + 3 * tl, C.tl_v, 3}, sN, val, sl);
-        const double tst = blob[C.o_tlstate + (size_t)tl * C.N + k];
-        { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; row(vN - val - tst - xs, 3, ix, g); }
-        { const int ix[3] = {1, 0, 8}; const double g[3] = {-1.0, -sl, -1.0}; row(-(vN + val + 1e3 - 10.0 - tst + xs), 3, ix, g); }
-    }
-    pwa(Tab{blob + C.o_vinc, blob + C.o_vinc + C.n_vinc, C.n_vinc}, sN, val, sl);
-    { const int ix[3] = {1, 0, 6}; const double g[3] = {-1.0, sl, -1.0}; row(-(vN - val + xv), 3, ix, g); }
-    const double stv = s_tv[(size_t)rt * C.N + k];
-    { const int ix[1] = {0}; const double g[1] = {1.0}; row(sN - (stv - C.h_min), 1, ix, g); }
-    { const int ix[3] = {0, 1, 8}; const double g[3] = {1.0, C.tau_min, -1.0}; row(sN + C.tau_min * vN - xs - stv, 3, ix, g); }
-    const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
-    { const int ix[3] = {0, 1, 7}; const double g[3] = {1.0, T_hwp + 2.0 * G_hwp * vN, -1.0}; row(sN + vN * T_hwp + vN * vN * G_hwp - xh - (stv - A_hwp), 3, ix, g); curv(n - 1, 1, 1, 2.0 * G_hwp); }
-    { const int ix[1] = {4}; const double g[1] = {-1.0}; row(C.Fm_min - Fm, 1, ix, g); }
-    { const int ix[1] = {4}; const double g[1] = {1.0}; row(Fm - C.Fm_max, 1, ix, g); }
-    { const int ix[1] = {5}; const double g[1] = {1.0}; row(Fb, 1, ix, g); }
-    for (int sidx = 6; sidx < 10; ++sidx) { const int ix[1] = {sidx}; const double g[1] = {-1.0}; row(-uk[sidx - 4], 1, ix, g); }
-    { const int ix[1] = {0}; const double g[1] = {-1.0}; row(-sN, 1, ix, g); }
-    { const int ix[1] = {1}; const double g[1] = {-1.0}; row(-vN, 1, ix, g); }
-    { const int ix[1] = {1}; const double g[1] = {1.0}; row(vN - V.v_max, 1, ix, g); }
-    if (C.has_goal) { const int ix[1] = {0}; const double g[1] = {1.0}; row(sN - C.s_goal, 1, ix, g); }
+    nlp_rows(C, blob, k, x1, uk, s_tv[(size_t)rt * C.N + k], row, curv);
 
     // ---- Q = H_L + T' G T,  q = gl + T'(gam + G (c, 0)),  T = [AB; 0 I] ----
     double GA[4][10], gx[4];
@@ -630,6 +665,12 @@ k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, double mu, 
         for (int a2 = 0; a2 < 4; ++a2) qi += AB[a2][i] * gx[a2];
         if (i >= 4) { qi += gam[i]; for (int b2 = 0; b2 < 4; ++b2) qi += G[i][b2] * cdef[b2]; }
         qout[i] = qi;
+        if (qlo) {                                          // gradient of the Lagrangian with the current multipliers
+            double ql = gl[i];
+            for (int a2 = 0; a2 < 4; ++a2) ql += AB[a2][i] * gaml[a2];
+            if (i >= 4) ql += gaml[i];
+            qlo[((size_t)rt * C.N + k) * 10 + i] = ql;
+        }
         for (int j2 = 0; j2 < 10; ++j2) {
             double acc = Q[i][j2];
             for (int a2 = 0; a2 < 4; ++a2) acc += AB[a2][i] * GA[a2][j2];
@@ -643,6 +684,97 @@ k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, double mu, 
     for (int a2 = 0; a2 < 4; ++a2) for (int i = 0; i < 10; ++i) ABout[a2 * 10 + i] = AB[a2][i];
     double* cout = co + ((size_t)rt * C.N + k) * 4;
     for (int a2 = 0; a2 < 4; ++a2) cout[a2] = cdef[a2];
+}
+
+
+// Rows and their directional derivative along a step: r [B][N][R] and Jr dy [B][N][R] with dy = (dchi_{k+1}, du_k).
+__global__ void __launch_bounds__(256)
+k_nlp_rowdir(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ s_tv, const double* __restrict__ chi,
+             const double* __restrict__ u, const double* __restrict__ dchi, const double* __restrict__ du, double* __restrict__ ro,
+             double* __restrict__ jdy) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)C.N * B) return;
+    const int rt = (int)(idx / C.N), k = (int)(idx % C.N);
+    const double* x1 = chi + ((size_t)rt * (C.N + 1) + k + 1) * 4;
+    const double* uk = u + ((size_t)rt * C.N + k) * 6;
+    double dy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (dchi) {
+        const double* d1 = dchi + ((size_t)rt * (C.N + 1) + k + 1) * 4;
+        const double* d2 = du + ((size_t)rt * C.N + k) * 6;
+        for (int i = 0; i < 4; ++i) dy[i] = d1[i];
+        for (int i = 0; i < 6; ++i) dy[4 + i] = d2[i];
+    }
+    double* rout = ro + ((size_t)rt * C.N + k) * C.R;
+    double* jout = jdy ? jdy + ((size_t)rt * C.N + k) * C.R : nullptr;
+    int n = 0;
+    auto row = [&](double rv, int cnt, const int* ix, const double* gv) {
+        double acc = 0.0;
+        for (int a2 = 0; a2 < cnt; ++a2) acc += gv[a2] * dy[ix[a2]];
+        rout[n] = rv;
+        if (jout) jout[n] = acc;
+        return n++;
+    };
+    auto curv = [&](int, int, int, double) {};
+    nlp_rows(C, blob, k, x1, uk, s_tv[(size_t)rt * C.N + k], row, curv);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Closed-loop nonlinear forward pass (include/eepacc_nlp.h: eepacc_nlp_rollout): u_k = u_base_k + alpha kf_k +
+// K_k (chi_k - chi_base_k), chi_{k+1} = f(chi_k, u_k) with the RK4 x 4 integrator.  Serial in k: one thread per route.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_nlp_rollout(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ alpha,
+              const double* __restrict__ chi0, const double* __restrict__ u0, const double* __restrict__ work,
+              double* __restrict__ chi1, double* __restrict__ u1) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const eepacc_vehicle& V = C.V;
+    const double lmass = V.lambda * V.m, mg = V.m * V.g, za = V.zeta_a;
+    const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
+    const double a = alpha ? alpha[r] : 0.0;
+    const double* cb = chi0 + (size_t)r * (C.N + 1) * 4;
+    const double* ub = u0 + (size_t)r * C.N * 6;
+    const double* wk = work ? work + (size_t)r * C.N * 50 : nullptr;
+    double* cn = chi1 + (size_t)r * (C.N + 1) * 4;
+    double* un = u1 + (size_t)r * C.N * 6;
+    double x[4] = {cb[0], cb[1], cb[2], cb[3]};
+    for (int i = 0; i < 4; ++i) cn[i] = x[i];
+    for (int k = 0; k < C.N; ++k) {
+        double uu[6];
+        for (int i = 0; i < 6; ++i) {
+            double d = 0.0;
+            if (wk) {
+                const double* Kr = wk + (size_t)k * 50 + i * 5;
+                d = a * Kr[4];
+                for (int j2 = 0; j2 < 4; ++j2) d += Kr[j2] * (x[j2] - cb[(size_t)k * 4 + j2]);
+            }
+            uu[i] = ub[(size_t)k * 6 + i] + d;
+            un[(size_t)k * 6 + i] = uu[i];
+        }
+        const double F = uu[0] + uu[1];
+        double th = 0.0, sl;
+        if (!C.flat) pwa(t_slope, x[0], th, sl);
+        const double grav = V.c_r * mg * cos(th) + mg * sin(th);
+        double s = x[0], v = x[1];
+        const double DT = C.Ts / 4;
+        for (int m2 = 0; m2 < 4; ++m2) {
+            const double a1 = (F - za * v * v - grav) / lmass;
+            const double v2 = v + (DT / 2) * a1;
+            const double a2 = (F - za * v2 * v2 - grav) / lmass;
+            const double v3 = v + (DT / 2) * a2;
+            const double a3 = (F - za * v3 * v3 - grav) / lmass;
+            const double v4 = v + DT * a3;
+            const double a4 = (F - za * v4 * v4 - grav) / lmass;
+            s = s + (DT / 6) * (v + 2 * v2 + 2 * v3 + v4);
+            v = v + (DT / 6) * (a1 + 2 * a2 + 2 * a3 + a4);
+        }
+        double th1 = 0.0;
+        if (!C.flat) pwa(t_slope, s, th1, sl);
+        const double p1 = (F - za * v * v - V.c_r * mg * cos(th1) - mg * sin(th1)) / lmass;
+        const double j1 = (p1 - x[2]) / C.Ts;
+        x[0] = s; x[1] = v; x[2] = p1; x[3] = j1;
+        for (int i = 0; i < 4; ++i) cn[(size_t)(k + 1) * 4 + i] = x[i];
+    }
 }
 
 }  // namespace
@@ -762,7 +894,8 @@ extern "C" int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream) {
 
 extern "C" int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev, const double* q_dev, const double* AB_dev,
                                   const double* c_dev, const double* reg_dev, const double reg_scale[6], double* dchi_dev,
-                                  double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, void* stream) {
+                                  double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, double* gnorm_dev,
+                                  const double* qlam_dev, void* stream) {
     if (B < 1 || N < 1 || !Q_dev || !q_dev || !AB_dev || !c_dev || !reg_dev || !reg_scale || !dchi_dev || !du_dev || !nu_dev ||
         !work_dev || !status_dev)
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_riccati: null argument, B < 1 or N < 1");
@@ -774,20 +907,44 @@ extern "C" int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev,
     RicScale sc;
     for (int i = 0; i < 6; ++i) sc.s[i] = reg_scale[i];
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, Q_dev, q_dev, AB_dev, c_dev, reg_dev, sc,
-                       dchi_dev, du_dev, nu_dev, work_dev, status_dev);
+                       dchi_dev, du_dev, nu_dev, work_dev, status_dev, gnorm_dev, qlam_dev);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
 
-extern "C" int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, double mu, double sigma, const double* s_tv_dev, const double* chi_dev,
+extern "C" int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, const double* mu_dev, double sigma, const double* s_tv_dev, const double* chi_dev,
                                  const double* u_dev, const double* lam_dev, const double* t_dev, const double* nu_dev,
-                                 double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, void* stream) {
-    if (!h || B < 1 || !s_tv_dev || !chi_dev || !u_dev || !lam_dev || !t_dev || !nu_dev || !Q_dev || !q_dev || !AB_dev || !c_dev)
+                                 double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, double* qlam_dev,
+                                 void* stream) {
+    if (!h || B < 1 || !mu_dev || !s_tv_dev || !chi_dev || !u_dev || !lam_dev || !t_dev || !nu_dev || !Q_dev || !q_dev || !AB_dev || !c_dev)
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_newton: null argument or B < 1");
     NLPCHK(hipSetDevice(h->device));
     const size_t units = (size_t)h->C.N * B;
-    hipLaunchKernelGGL(k_nlp_newton, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, mu, sigma,
-                       s_tv_dev, chi_dev, u_dev, lam_dev, t_dev, nu_dev, Q_dev, q_dev, AB_dev, c_dev, rows_dev);
+    hipLaunchKernelGGL(k_nlp_newton, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, mu_dev, sigma,
+                       s_tv_dev, chi_dev, u_dev, lam_dev, t_dev, nu_dev, Q_dev, q_dev, AB_dev, c_dev, rows_dev, qlam_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alpha_dev, const double* chi_dev, const double* u_dev,
+                                  const double* work_dev, double* chi_new_dev, double* u_new_dev, void* stream) {
+    if (!h || B < 1 || !chi_dev || !u_dev || !chi_new_dev || !u_new_dev || (work_dev && !alpha_dev))
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_rollout: null argument or B < 1");
+    NLPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_nlp_rollout, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, alpha_dev, chi_dev, u_dev,
+                       work_dev, chi_new_dev, u_new_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_rowdir(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const double* chi_dev, const double* u_dev,
+                                 const double* dchi_dev, const double* du_dev, double* rows_dev, double* jdy_dev, void* stream) {
+    if (!h || B < 1 || !s_tv_dev || !chi_dev || !u_dev || !rows_dev || (jdy_dev && (!dchi_dev || !du_dev)))
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_rowdir: null argument or B < 1");
+    NLPCHK(hipSetDevice(h->device));
+    const size_t units = (size_t)h->C.N * B;
+    hipLaunchKernelGGL(k_nlp_rowdir, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->C, h->d_blob, B, s_tv_dev,
+                       chi_dev, u_dev, jdy_dev ? dchi_dev : nullptr, du_dev, rows_dev, jdy_dev);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }

@@ -19,7 +19,7 @@ import numpy as np
 
 from ._abi import Vehicle, make_vehicle
 
-__all__ = ["pwa", "build_tables", "NlpEvaluator", "nlp_rows", "postprocess", "riccati_batched"]
+__all__ = ["pwa", "build_tables", "NlpEvaluator", "NlpSolver", "car_following_start", "nlp_rows", "postprocess", "riccati_batched"]
 
 
 def pwa(x, xs, ys):
@@ -194,8 +194,10 @@ def _bind(lib):
     lib.eepacc_nlp_destroy.restype = None
     lib.eepacc_nlp_eval.argtypes = [vp, C.c_int] + [vp] * 9
     lib.eepacc_nlp_synchronize.argtypes = [vp, vp]
-    lib.eepacc_nlp_newton.argtypes = [vp, C.c_int, C.c_double, C.c_double] + [vp] * 12
-    lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp]
+    lib.eepacc_nlp_newton.argtypes = [vp, C.c_int, vp, C.c_double] + [vp] * 13
+    lib.eepacc_nlp_rowdir.argtypes = [vp, C.c_int] + [vp] * 8
+    lib.eepacc_nlp_rollout.argtypes = [vp, C.c_int] + [vp] * 7
+    lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -312,10 +314,13 @@ class NlpEvaluator:
         AB = torch.empty((B, N, 4, 10), dtype=torch.float64, device=dev)
         c = torch.empty((B, N, 4), dtype=torch.float64, device=dev)
         rows = torch.empty((B, N, R), dtype=torch.float64, device=dev)
+        qlam = torch.empty((B, N, 10), dtype=torch.float64, device=dev)
+        self.last_qlam = qlam
         stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = self.lib.eepacc_nlp_newton(self.h, B, float(mu), float(sigma), s_tv.data_ptr(), chi.data_ptr(), u.data_ptr(),
+        mu_t = (mu if isinstance(mu, torch.Tensor) else torch.full((B,), float(mu), dtype=torch.float64)).to(device=dev, dtype=torch.float64).contiguous()
+        rc = self.lib.eepacc_nlp_newton(self.h, B, mu_t.data_ptr(), float(sigma), s_tv.data_ptr(), chi.data_ptr(), u.data_ptr(),
                                         lam.data_ptr(), t.data_ptr(), nu.data_ptr(), Q.data_ptr(), q.data_ptr(), AB.data_ptr(),
-                                        c.data_ptr(), rows.data_ptr(), stream)
+                                        c.data_ptr(), rows.data_ptr(), qlam.data_ptr(), stream)
         if rc != 0:
             raise self._err("eepacc_nlp_newton failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
         return Q, q, AB, c, rows
@@ -328,7 +333,8 @@ class NlpEvaluator:
             raise self._err("eepacc_nlp_synchronize failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
 
 
-def riccati_batched(Q, q, AB, c, reg, reg_scale=(1e-6, 1e-6, 1e-10, 1e-10, 1e-10, 1e-10), device: int = 0):
+def riccati_batched(Q, q, AB, c, reg, reg_scale=(1e-6, 1e-6, 1e-10, 1e-10, 1e-10, 1e-10), device: int = 0, full: bool = False,
+                    qlam=None):
     """include/eepacc_nlp.h: eepacc_nlp_riccati.  Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4], reg [B]
     (numpy or CUDA tensors).  Returns (dchi [B][N+1][4], du [B][N][6], nu [B][N+1][4], status [B]) as CUDA tensors."""
     import torch
@@ -348,12 +354,16 @@ def riccati_batched(Q, q, AB, c, reg, reg_scale=(1e-6, 1e-6, 1e-10, 1e-10, 1e-10
     nu = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
     work = torch.empty((B, N, 50), dtype=torch.float64, device=dev)
     status = torch.empty(B, dtype=torch.int32, device=dev)
+    gnorm = torch.empty(B, dtype=torch.float64, device=dev)
     sc = (C.c_double * 6)(*[float(x) for x in reg_scale])
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = lib.eepacc_nlp_riccati(device, B, N, Q.data_ptr(), q.data_ptr(), AB.data_ptr(), c.data_ptr(), reg.data_ptr(), sc,
-                                dchi.data_ptr(), du.data_ptr(), nu.data_ptr(), work.data_ptr(), status.data_ptr(), stream)
+                                dchi.data_ptr(), du.data_ptr(), nu.data_ptr(), work.data_ptr(), status.data_ptr(), gnorm.data_ptr(),
+                                qlam.data_ptr() if qlam is not None else None, stream)
     if rc != 0:
         raise EepaccError("eepacc_nlp_riccati failed (%d): %s" % (rc, lib.eepacc_last_error().decode()))
+    if full:
+        return dchi, du, nu, status, work, gnorm
     return dchi, du, nu, status
 
 
@@ -378,4 +388,239 @@ def postprocess(OPTsettings: Dict[str, Any], V: Dict[str, float], v_opt, Fm_opt,
                    cost_j=W[2] * np.cumsum(np.asarray(j_opt, float)[:len(P)] ** 2),
                    cost_xi_v=W[3] * np.cumsum(sl[:, 0]), cost_xi_h=W[4] * np.cumsum(sl[:, 1]),
                    cost_xi_s=W[5] * np.cumsum(sl[:, 2]), cost_xi_f=W[6] * np.cumsum(sl[:, 3]))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# interior-point iteration over the GPU operators (host logic only: step lengths, barrier and Levenberg updates)
+# ----------------------------------------------------------------------------------------------
+class NlpSolver(NlpEvaluator):
+    """Batched structured interior-point solver of RunOpt_NLP's problem: every route of the batch runs the iteration of
+    DESIGN.md section 3.8 (Newton system assembled by eepacc_nlp_newton, factorised by eepacc_nlp_riccati, closed-loop
+    nonlinear forward pass eepacc_nlp_rollout, rows / objective by eepacc_nlp_rowdir / eepacc_nlp_eval); this class holds
+    only the per-route scalars (barrier parameter, Levenberg term, step lengths) and the accept / reject logic, as
+    elementwise tensor operations over the batch.  Convergence domain: see DESIGN.md section 7 (short routes from the
+    car-following start; the full route from a start near the solution)."""
+
+    REG_SCALE = (1e-6, 1e-6, 1e-10, 1e-10, 1e-10, 1e-10)
+
+    def _theta(self, s):
+        import torch
+        if self.tables["flat"]:
+            return torch.zeros_like(s)
+        xs = torch.as_tensor(self.tables["slope"][0], dtype=torch.float64, device=s.device)
+        ys = torch.as_tensor(self.tables["slope"][1], dtype=torch.float64, device=s.device)
+        i = (torch.searchsorted(xs, s.contiguous(), right=True) - 1).clamp(0, len(xs) - 2)
+        dx = xs[i + 1] - xs[i]
+        sl = torch.where(dx > 0, (ys[i + 1] - ys[i]) / torch.where(dx > 0, dx, torch.ones_like(dx)), torch.zeros_like(dx))
+        return ys[i] + sl * (s - xs[i])
+
+    def _rowdir(self, s_tv, chi, u, dchi=None, du=None):
+        import torch
+        B = chi.shape[0]
+        rows = torch.empty((B, self.N, self.R), dtype=torch.float64, device=chi.device)
+        jdy = torch.empty_like(rows) if dchi is not None else None
+        stream = torch.cuda.current_stream(chi.device).cuda_stream
+        rc = self.lib.eepacc_nlp_rowdir(self.h, B, s_tv.data_ptr(), chi.data_ptr(), u.data_ptr(),
+                                        dchi.data_ptr() if dchi is not None else None, du.data_ptr() if du is not None else None,
+                                        rows.data_ptr(), jdy.data_ptr() if jdy is not None else None, stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_rowdir failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return rows, jdy
+
+    def rollout(self, chi, u, work=None, alpha=None):
+        import torch
+        B = chi.shape[0]
+        chi_n, u_n = torch.empty_like(chi), torch.empty_like(u)
+        stream = torch.cuda.current_stream(chi.device).cuda_stream
+        rc = self.lib.eepacc_nlp_rollout(self.h, B, alpha.data_ptr() if alpha is not None else None, chi.data_ptr(), u.data_ptr(),
+                                         work.data_ptr() if work is not None else None, chi_n.data_ptr(), u_n.data_ptr(), stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_rollout failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return chi_n, u_n
+
+    def _values(self, s_tv, s_tv_bm, chi, u, sigma):
+        """Scaled objective [B] and rows [B][N][R] at a point whose states are the rollout of its controls."""
+        import torch
+        X = torch.stack([chi[:, :, 0], chi[:, :, 1], self._theta(chi[:, :, 0]), chi[:, :, 3]], dim=2)      # [B][N+1][4]
+        o = self.eval(s_tv_bm, X.permute(1, 2, 0).contiguous(), u.permute(1, 2, 0).contiguous(), want_grad=False)
+        rows, _ = self._rowdir(s_tv, chi, u)
+        return sigma * o["J"], rows
+
+    def start_from_controls(self, s_tv, chi0, forces, margin=1.0):
+        """Start point from force trajectories [B][N][2] (Fm, Fb <= 0): states by rollout, slacks `margin` above what the
+        rows need.  chi0 [B][4] = (s_0, v_0, p_0, 0)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        forces = torch.as_tensor(forces, dtype=torch.float64, device=dev)
+        B, N = forces.shape[0], self.N
+        u = torch.zeros((B, N, 6), dtype=torch.float64, device=dev)
+        u[:, :, :2] = forces
+        chi = torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev)
+        chi[:, 0] = torch.as_tensor(chi0, dtype=torch.float64, device=dev)
+        chi, u = self.rollout(chi, u)
+        s_tv = torch.as_tensor(s_tv, dtype=torch.float64, device=dev).contiguous()
+        r0, _ = self._rowdir(s_tv, chi, u)
+        nt = 2 * self.n_tl
+        zero = torch.zeros((), dtype=torch.float64, device=dev)
+        u[:, :, 2] = torch.maximum(r0[:, :, 13 + nt], zero) + margin
+        u[:, :, 3] = torch.maximum(r0[:, :, 16 + nt], zero) + margin
+        u[:, :, 4] = torch.maximum(torch.maximum(r0[:, :, 12:13 + nt].amax(dim=2), r0[:, :, 15 + nt]), zero) + margin
+        u[:, :, 5] = torch.maximum(r0[:, :, 0:12].amax(dim=2), zero) + margin
+        return chi, u
+
+    def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
+              reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False):
+        """s_tv [B][N], chi [B][N+1][4], u [B][N][6] (a start whose states are the rollout of its controls).
+        Returns dict(chi, u, J [B], status [B] (0 KKT point to `tol`, 1 iteration limit, 2 Levenberg limit), iters [B],
+        kkt [B][3], lam, t)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        f64 = torch.float64
+        s_tv = torch.as_tensor(s_tv, dtype=f64, device=dev).contiguous()
+        s_tv_bm = s_tv.t().contiguous()
+        chi = torch.as_tensor(chi, dtype=f64, device=dev).contiguous().clone()
+        u = torch.as_tensor(u, dtype=f64, device=dev).contiguous().clone()
+        B, N, R, sigma = chi.shape[0], self.N, self.R, float(obj_scale)
+        cost, r = self._values(s_tv, s_tv_bm, chi, u, sigma)
+        t = torch.clamp(-r, min=1e-2)
+        mu = torch.full((B,), float(mu_init), dtype=f64, device=dev)
+        lam = mu[:, None, None] / t
+        nu = torch.zeros((B, N + 1, 4), dtype=f64, device=dev)
+        rho = torch.ones(B, dtype=f64, device=dev)
+        reg_last = torch.zeros(B, dtype=f64, device=dev)
+        status = torch.ones(B, dtype=torch.int32, device=dev)
+        iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        active = torch.ones(B, dtype=torch.bool, device=dev)
+        kkt = torch.zeros((B, 3), dtype=f64, device=dev)
+        inf = torch.full((B,), float("inf"), dtype=f64, device=dev)
+        b3 = lambda x: x[:, None, None]
+        for it in range(max_iter):
+            # Newton system at the current point; the barrier parameter falls while its subproblem is solved
+            for _ in range(8):
+                Q, q, AB, c, rows = self.newton(s_tv, chi, u, lam, t, nu, mu, sigma)
+                rg = r + t
+                dchi, du, nu_new, st, work, gnorm = riccati_batched(Q, q, AB, c, reg_last, self.REG_SCALE, self.device, full=True, qlam=self.last_qlam)
+                e_dual = torch.where(st == 0, gnorm, inf)
+                rows_i = rg > 1e-9 * (1.0 + t)
+                e_prim = (rg * rows_i).amax(dim=(1, 2))
+                lt = lam * t
+                e_comp0 = lt.amax(dim=(1, 2))
+                e_compm = (lt - b3(mu)).abs().amax(dim=(1, 2))
+                err0 = torch.maximum(torch.maximum(e_dual, e_prim), e_comp0)
+                done = active & (err0 <= tol)
+                kkt[active] = torch.stack([e_dual, e_prim, e_comp0], dim=1)[active]
+                status[done] = 0
+                active = active & ~done
+                dec = active & (mu > mu_min) & (torch.maximum(torch.maximum(e_dual, e_prim), e_compm) <= kappa_eps * mu)
+                if not bool(dec.any()):
+                    break
+                mu = torch.where(dec, torch.clamp(torch.minimum(kappa_mu * mu, mu ** theta_mu), min=mu_min), mu)
+            if verbose:
+                print("it %3d active %d  J %s  mu %s  dual %s" % (it, int(active.sum()), (cost[:3] / sigma).tolist(), mu[:3].tolist(),
+                                                                   e_dual[:3].tolist()), flush=True)
+            if not bool(active.any()):
+                break
+            iters += active.to(torch.int32)
+            # Levenberg loop: the regularisation of a route grows until its factorisation has the right inertia and the
+            # line search accepts a step
+            reg = reg_last.clone()
+            accepted = ~active
+            new_chi, new_u, new_t, new_cost, new_lam, new_nu = chi.clone(), u.clone(), t.clone(), cost.clone(), lam.clone(), nu.clone()
+            ls_used = torch.zeros(B, dtype=torch.int32, device=dev)
+            first = True
+            for _attempt in range(40):
+                need = active & ~accepted
+                if not bool(need.any()):
+                    break
+                if not first:
+                    dchi, du, nu_new, st, work, gnorm = riccati_batched(Q, q, AB, c, reg, self.REG_SCALE, self.device, full=True)
+                first = False
+                ok = st == 0
+                _, jdy = self._rowdir(s_tv, chi, u, dchi, du)
+                Dg = lam / t
+                dt = -rg - jdy
+                lam_new = b3(mu) / t + Dg * rg + Dg * jdy
+                dlam = lam_new - lam
+                tau = torch.clamp(1.0 - mu, min=tau_min)
+                big = torch.full_like(t, float("inf"))
+                a_p = torch.clamp(torch.where(dt < 0, -b3(tau) * t / torch.where(dt < 0, dt, -torch.ones_like(dt)), big).amin(dim=(1, 2)), max=1.0)
+                a_d = torch.clamp(torch.where(dlam < 0, -b3(tau) * lam / torch.where(dlam < 0, dlam, -torch.ones_like(dlam)), big).amin(dim=(1, 2)), max=1.0)
+                infeas = (rg * rows_i).sum(dim=(1, 2))
+                lam_i = (lam_new.abs() * rows_i).amax(dim=(1, 2))
+                rho = torch.where(infeas > 0, torch.maximum(rho, 1.1 * lam_i), rho)
+                phi0 = cost - mu * torch.log(t).sum(dim=(1, 2)) + rho * infeas
+                a = a_p.clone()
+                acc_now = torch.zeros(B, dtype=torch.bool, device=dev)
+                for ls in range(max_ls):
+                    trial = need & ok & ~acc_now
+                    if not bool(trial.any()):
+                        break
+                    chi_t, u_t = self.rollout(chi, u, work, a)
+                    cost_t, r_t = self._values(s_tv, s_tv_bm, chi_t, u_t, sigma)
+                    t_t = torch.where(rows_i, torch.maximum(-r_t, t + b3(a) * dt), -r_t)
+                    feas = (t_t >= (1.0 - b3(tau)) * t).all(dim=2).all(dim=1)
+                    inf_t = ((r_t + t_t) * rows_i).sum(dim=(1, 2))
+                    phi_t = cost_t - mu * torch.log(torch.clamp(t_t, min=1e-300)).sum(dim=(1, 2)) + rho * inf_t
+                    good = trial & feas & (phi_t <= phi0 + 1e-13 * phi0.abs())
+                    if bool(good.any()):
+                        new_chi[good], new_u[good], new_t[good], new_cost[good] = chi_t[good], u_t[good], t_t[good], cost_t[good]
+                        lam_g = lam + b3(a_d) * dlam
+                        new_lam[good] = lam_g[good]
+                        new_nu[good] = nu_new[good]
+                        ls_used[good] = ls
+                    acc_now = acc_now | good
+                    a = torch.where(trial & ~good, 0.5 * a, a)
+                accepted = accepted | acc_now
+                grow = need & ~acc_now
+                reg = torch.where(grow, torch.clamp(reg * 8.0, min=reg_first), reg)
+                lost = grow & (reg > reg_max)
+                status[lost] = 2
+                active = active & ~lost
+            moved = accepted & active
+            chi, u, t, cost, nu = new_chi, new_u, new_t, new_cost, new_nu
+            lam = torch.where(b3(moved), torch.minimum(torch.maximum(new_lam, b3(mu) / (1e10 * t)), 1e10 * b3(mu) / t), lam)
+            _, r = self._values(s_tv, s_tv_bm, chi, u, sigma)             # rows of the point every route now stands at
+            reg_last = torch.where(moved, torch.where(ls_used <= 1, reg / 3.0, reg), reg_last)
+            reg_last = torch.where(reg_last < reg_first, torch.zeros_like(reg_last), reg_last)
+        return dict(chi=chi, u=u, J=cost / sigma, status=status, iters=iters, kkt=kkt, lam=lam, t=t)
+
+
+def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables: Dict[str, Any], s_tv) -> np.ndarray:
+    """Force trajectory [N][2] of a plain car-following rollout (speed target = min(speed limit - 1, stop profile,
+    desired-headway speed behind the lead vehicle), acceleration (target - v)/2 s clipped to [-2, 1.2] m/s^2): the start
+    the solver is given where the reference starts IPOPT from z0 = 0 (RunOpt_NLP.m:348)."""
+    N, Ts = int(tables["N"]), float(OPTsettings["Ts"])
+    lm = V["lambda"] * V["m"]
+    mg = V["m"] * V["g"]
+    Fm_min = -V["phi"] * V["T_m_max"] / V["eta_TF"]
+    s, v = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
+    out = np.zeros((N, 2))
+    flat = tables["flat"]
+    for k in range(N):
+        th = 0.0 if flat else float(pwa(s, *tables["slope"])[0])
+        grav = V["c_r"] * mg * math.cos(th) + mg * math.sin(th)
+        vlim = float(pwa(s + 2.0 * v, *tables["vlim"])[0])
+        stop = float(pwa(s + 2.0 * v, *tables["stop"])[0])
+        gap = float(s_tv[min(k + 1, N - 1)]) - 2.0 - 1.0 - s
+        vt = max(0.0, min(vlim - 1.0, stop - 0.5, max(0.0, gap / 3.0)))
+        a = min(1.2, max(-2.0, (vt - v) / 2.0))
+        if v + a * Ts < 0.0:
+            a = -v / Ts
+        F = lm * a + V["zeta_a"] * v * v + grav
+        Fm, Fb = (F, -1.0) if F > Fm_min * 0.5 else (Fm_min * 0.5, F - Fm_min * 0.5)
+        Fm += 1.0
+        out[k] = (Fm, Fb)
+        Ft = Fm + Fb
+        DT = Ts / 4
+        for _ in range(4):                                  # the interval's RK4 x 4 (RunOpt_NLP.m:262-278)
+            a1 = (Ft - V["zeta_a"] * v * v - grav) / lm
+            v2 = v + DT / 2 * a1
+            a2 = (Ft - V["zeta_a"] * v2 * v2 - grav) / lm
+            v3 = v + DT / 2 * a2
+            a3 = (Ft - V["zeta_a"] * v3 * v3 - grav) / lm
+            v4 = v + DT * a3
+            a4 = (Ft - V["zeta_a"] * v4 * v4 - grav) / lm
+            s += DT / 6 * (v + 2 * v2 + 2 * v3 + v4)
+            v += DT / 6 * (a1 + 2 * a2 + 2 * a3 + a4)
     return out

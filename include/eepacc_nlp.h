@@ -89,11 +89,15 @@ int eepacc_nlp_synchronize(eepacc_nlp_handle* h, void* stream);
  * (route, interval) the exact Lagrangian Hessian (second-order sensitivities of the RK4 x 4 integrator and of the
  * running cost, row curvature), the barrier terms of all rows and the linearised dynamics, condensed to the blocks
  * eepacc_nlp_riccati takes.  Route-major arrays: chi [B][N+1][4], u [B][N][6], lam / t [B][N][R] (multipliers and slacks of
- * the rows, R = eepacc_nlp_rows), nu [B][N+1][4] (costates), s_tv [B][N]; mu = barrier parameter, sigma = objective scale.
- * Outputs Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4] and, if not NULL, the row values [B][N][R]. */
-int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, double mu, double sigma, const double* s_tv_dev, const double* chi_dev,
+ * the rows, R = eepacc_nlp_rows), nu [B][N+1][4] (costates), s_tv [B][N]; mu [B] = barrier parameter of each route, sigma =
+ * objective scale.
+ * Outputs Q [B][N][10][10], q [B][N][10], AB [B][N][4][10], c [B][N][4] and, if not NULL, the row values [B][N][R] and
+ * qlam [B][N][10], the stage gradient of the Lagrangian with the multipliers lam (eepacc_nlp_riccati turns it into the dual
+ * residual). */
+int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, const double* mu_dev, double sigma, const double* s_tv_dev, const double* chi_dev,
                       const double* u_dev, const double* lam_dev, const double* t_dev, const double* nu_dev,
-                      double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, void* stream);
+                      double* Q_dev, double* q_dev, double* AB_dev, double* c_dev, double* rows_dev, double* qlam_dev,
+                      void* stream);
 
 /* Stage-wise factorisation of one Newton system per route: the linear solve inside every interior-point iteration
  * (what IPOPT hands to MUMPS in the reference, RunOpt_NLP.m:505-510), exploiting that the problem is an optimal-control
@@ -107,10 +111,27 @@ int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, double mu, double sigma, cons
  *   dchi_dev [B][N+1][4], du_dev [B][N][6], nu_dev [B][N+1][4]   step and costates (nu_0 and nu_N are 0)
  *   work_dev [B][N][50]    gains and value-function blocks between the two sweeps
  *   status_dev [B]         0, or 1 + the first stage (counted from the end) whose control block is not positive definite
- *                          (pivot <= 1e-10 x its diagonal entry): the caller raises reg and calls again */
+ *                          (pivot <= 1e-10 x its diagonal entry): the caller raises reg and calls again
+ *   gnorm_dev [B]          (may be NULL) largest |reduced gradient| over the stages and controls: the dual residual of the
+ *                          barrier problem at the point the system was assembled at; with qlam_dev (eepacc_nlp_newton)
+ *                          the one of the Lagrangian with the current multipliers (adjoint recursion along the sweep) */
 int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev, const double* q_dev, const double* AB_dev,
                        const double* c_dev, const double* reg_dev, const double reg_scale[6], double* dchi_dev,
-                       double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, void* stream);
+                       double* du_dev, double* nu_dev, double* work_dev, int32_t* status_dev, double* gnorm_dev,
+                       const double* qlam_dev, void* stream);
+
+/* Row values r [B][N][R] at (chi, u) and, if jdy_dev is not NULL, their directional derivative Jr (dchi_{k+1}, du_k) along a
+ * step: what the step-length rules and the multiplier update of an interior-point iteration need. */
+int eepacc_nlp_rowdir(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const double* chi_dev, const double* u_dev,
+                      const double* dchi_dev, const double* du_dev, double* rows_dev, double* jdy_dev, void* stream);
+
+
+/* Closed-loop nonlinear forward pass of a step (the dynamics hold at every iterate of the solver): for every route
+ *   u_k = u_k + alpha * kf_k + K_k (chi_k_new - chi_k),   chi_{k+1}_new = f(chi_k_new, u_k)   (RK4 x 4, RunOpt_NLP.m:262-278)
+ * with the gains K | kf that eepacc_nlp_riccati left in its work array [B][N][50].  work_dev = NULL: plain rollout of
+ * the controls (alpha ignored).  chi [B][N+1][4] (node 0 is kept), u [B][N][6], alpha [B]. */
+int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alpha_dev, const double* chi_dev, const double* u_dev,
+                       const double* work_dev, double* chi_new_dev, double* u_new_dev, void* stream);
 
 #ifdef __cplusplus
 }

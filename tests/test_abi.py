@@ -91,7 +91,7 @@ def test_nlp_header_symbols_and_layout(lib):
     from eepacc_mpc_casadi_matlab_amd import nlp
     hdr = open(os.path.join(ROOT, "include", "eepacc_nlp.h")).read()
     declared = sorted(set(re.findall(r"\b(eepacc_nlp_[a-z_0-9]+)\s*\(", hdr)))
-    assert declared == ["eepacc_nlp_create", "eepacc_nlp_destroy", "eepacc_nlp_eval", "eepacc_nlp_newton", "eepacc_nlp_riccati", "eepacc_nlp_rows",
+    assert declared == ["eepacc_nlp_create", "eepacc_nlp_destroy", "eepacc_nlp_eval", "eepacc_nlp_newton", "eepacc_nlp_riccati", "eepacc_nlp_rollout", "eepacc_nlp_rowdir", "eepacc_nlp_rows",
                         "eepacc_nlp_sizeof_problem", "eepacc_nlp_synchronize"]
     for name in declared:
         assert hasattr(lib, name), name

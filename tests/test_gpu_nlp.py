@@ -250,3 +250,74 @@ def test_newton_assembly_and_step_against_oracle(features):
     assert o[3][0].item() == 0
     assert np.abs(o[1][0].cpu().numpy() - du).max() <= 1e-7 * max(1.0, np.abs(du).max())
     assert np.abs(o[0][0].cpu().numpy() - dchi).max() <= 1e-7 * max(1.0, np.abs(dchi).max())
+
+
+def _gpu_start(sol, P, OPT, V):
+    from eepacc_mpc_casadi_matlab_amd.nlp import car_following_start
+    forces = car_following_start(OPT, V, sol.tables, P.s_tv)
+    chi0 = np.array([[P.s0, P.v0, -P.drag(P.v0, float(P.theta(np.array([P.s0]))[0][0])) / (V["lambda"] * V["m"]), 0.0]])
+    return sol.start_from_controls(P.s_tv[None], chi0, forces[None], margin=1.0)
+
+
+@pytest.mark.parametrize("t_sim", [20.0, 60.0])
+def test_solver_short_routes_against_oracle(t_sim):
+    """The batched interior-point solver over the GPU operators on the first 20 s / 60 s of the reference scenario: KKT
+    point (1e-7, scaled problem) from the car-following start, objective equal to the oracle solver's (same method, same
+    start: 1e-6 relative), rows hold, states are the integrator's rollout of the controls."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    OPT["t_sim"] = t_sim
+    P = M.NlpProblem(OPT, V, s_tv)
+    sol = NlpSolver(OPT, V)
+    chi, u = _gpu_start(sol, P, OPT, V)
+    c_ref, u_ref = M.initial_point(P)
+    assert np.abs(chi[0].cpu().numpy() - c_ref).max() < 1e-9 and np.abs(u[0].cpu().numpy() - u_ref).max() < 1e-6
+    R = sol.solve(P.s_tv[None], chi, u, max_iter=80)
+    Ro = M.solve(P, M.NlpOptions(max_iter=80))
+    assert Ro["status"] == 0 and int(R["status"][0]) == 0, (Ro["status"], R["status"], R["kkt"])
+    Jg = float(R["J"][0])
+    assert abs(Jg / Ro["J"] - 1) < 1e-6, (Jg, Ro["J"])
+    chi_g, u_g = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy()
+    assert M._rows(P, chi_g[1:], u_g, np.arange(P.N))[0].max() < 1e-7
+    ref = P.eval_reference_form(chi_g[:, 0], chi_g[:, 1], np.zeros(P.N + 1), chi_g[:, 3], u_g)
+    assert np.abs(ref["eq"]).max() < 1e-9 and abs(ref["J"] / Jg - 1) < 1e-12
+
+
+def test_solver_batch_and_saved_solution():
+    """(i) Four routes with different lead traces in one batch = four single-route solves.  (ii) Objective-level parity
+    with the reference where the iteration converges on the full 870-interval route: started from the saved IPOPT
+    controls (states re-integrated, slacks 1e-3 above the rows, barrier 1e-4) the GPU solver reaches a KKT point whose
+    objective equals the saved point's to 1e-6 relative and whose speeds stay within 0.05 m/s of the saved ones."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    OPT["t_sim"] = 20.0
+    P = M.NlpProblem(OPT, V, s_tv)
+    sol = NlpSolver(OPT, V)
+    offs = np.array([0.0, 3.0, 8.0, 20.0])
+    starts, singles = [], []
+    for o in offs:
+        P.s_tv = s_tv[:P.N] + o
+        c, w = _gpu_start(sol, P, OPT, V)
+        starts.append((c, w))
+        singles.append(sol.solve(P.s_tv[None], c, w, max_iter=80))
+    import torch
+    stv_b = np.stack([s_tv[:P.N] + o for o in offs])
+    Rb = sol.solve(stv_b, torch.cat([c for c, _ in starts]), torch.cat([w for _, w in starts]), max_iter=80)
+    for i in range(4):
+        assert int(Rb["status"][i]) == 0 and int(singles[i]["status"][0]) == 0
+        assert abs(float(Rb["J"][i]) / float(singles[i]["J"][0]) - 1) < 1e-9
+    assert len({round(float(x), 3) for x in Rb["J"]}) == 4                      # the routes really differ
+    # (ii)
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    P = M.NlpProblem(OPT, V, s_tv)
+    G = load_golden("abo_nlp")
+    sol = NlpSolver(OPT, V)
+    forces = np.stack([G["Fm_opt"], np.minimum(G["Fb_opt"], -1e-3)], axis=1)
+    chi0 = np.array([[0.0, 0.0, -P.drag(0.0, 0.0) / (V["lambda"] * V["m"]), 0.0]])
+    chi, u = sol.start_from_controls(P.s_tv[None], chi0, forces[None], margin=1e-3)
+    R = sol.solve(P.s_tv[None], chi, u, max_iter=60, mu_init=1e-4)
+    U = np.stack([G[k] for k in ("Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt")], axis=1)
+    J_saved = P.eval_reference_form(G["s_opt"], G["v_opt"], G["theta_opt"], G["j_opt"], U)["J"]
+    assert int(R["status"][0]) == 0, (R["status"], R["kkt"], R["iters"])
+    assert abs(float(R["J"][0]) / J_saved - 1) < 1e-6
+    assert np.abs(R["chi"][0, :, 1].cpu().numpy() - G["v_opt"]).max() < 0.05
