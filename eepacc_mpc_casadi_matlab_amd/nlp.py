@@ -19,7 +19,7 @@ import numpy as np
 
 from ._abi import Vehicle, make_vehicle
 
-__all__ = ["pwa", "build_tables", "NlpEvaluator", "NlpSolver", "car_following_start", "nlp_rows", "postprocess", "riccati_batched"]
+__all__ = ["pwa", "build_tables", "NlpEvaluator", "NlpSolver", "RunOpt_NLP", "car_following_start", "nlp_rows", "postprocess", "riccati_batched"]
 
 
 def pwa(x, xs, ys):
@@ -623,4 +623,38 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
             a4 = (Ft - V["zeta_a"] * v4 * v4 - grav) / lm
             s += DT / 6 * (v + 2 * v2 + 2 * v3 + v4)
             v += DT / 6 * (a1 + 2 * a2 + 2 * a3 + a4)
+    return out
+
+
+def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,
+               max_iter: int = 300, mu_init: float | None = None) -> Dict[str, Any]:
+    """`optSol = RunOpt_NLP(OPTsettings)` (ABO/RunOpt_NLP.m, called from ABO/Main.m:124): same fields as the reference's
+    struct.  `OPTsettings["s_tv"]` is the lead trace of Main.m:88.  The start is the car-following rollout unless
+    `start_forces` [N][2] (Fm, Fb) is given; `exitMessage` is 'Solve_Succeeded' for a KKT point, otherwise
+    'Maximum_Iterations_Exceeded' / 'Restoration_Failed' (IPOPT's names for the two other outcomes) -- see DESIGN.md
+    section 7 for where the iteration converges."""
+    import time
+    from .settings import SetVehicleParameters
+    V = V or SetVehicleParameters(OPTsettings.get("tree", "ABO"))
+    sol = NlpSolver(OPTsettings, V, device=device)
+    N = sol.N
+    s_tv = np.asarray(OPTsettings["s_tv"], dtype=np.float64)[:N]
+    s0, v0 = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
+    th0 = 0.0 if sol.tables["flat"] else float(pwa(s0, *sol.tables["slope"])[0])
+    p0 = -(V["zeta_a"] * v0 * v0 + V["c_r"] * V["m"] * V["g"] * math.cos(th0) + V["m"] * V["g"] * math.sin(th0)) / (V["lambda"] * V["m"])
+    warm = start_forces is not None
+    forces = np.asarray(start_forces, float) if warm else car_following_start(OPTsettings, V, sol.tables, s_tv)
+    chi, u = sol.start_from_controls(s_tv[None], np.array([[s0, v0, p0, 0.0]]), forces[None], margin=1e-3 if warm else 1.0)
+    t0 = time.perf_counter()
+    R = sol.solve(s_tv[None], chi, u, max_iter=max_iter, mu_init=(1e-4 if warm else 1.0) if mu_init is None else mu_init)
+    sol.synchronize()
+    tSolve = time.perf_counter() - t0
+    chi, u = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy()
+    theta = np.zeros(N + 1) if sol.tables["flat"] else pwa(chi[:, 0], *sol.tables["slope"])[0]
+    out = dict(s_velInc=sol.tables["vinc"][0], v_velInc=sol.tables["vinc"][1], tSolve=tSolve,
+               exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(R["status"][0])],
+               s_opt=chi[:, 0], v_opt=chi[:, 1], theta_opt=theta, j_opt=chi[:, 3], Fm_opt=u[:, 0], Fb_opt=u[:, 1],
+               xi_v_opt=u[:, 2], xi_h_opt=u[:, 3], xi_s_opt=u[:, 4], xi_f_opt=u[:, 5],
+               J=float(R["J"][0]), iterations=int(R["iters"][0]))
+    out.update(postprocess(OPTsettings, V, chi[:, 1], u[:, 0], chi[:, 3], u[:, 2:]))
     return out

@@ -321,3 +321,29 @@ def test_solver_batch_and_saved_solution():
     assert int(R["status"][0]) == 0, (R["status"], R["kkt"], R["iters"])
     assert abs(float(R["J"][0]) / J_saved - 1) < 1e-6
     assert np.abs(R["chi"][0, :, 1].cpu().numpy() - G["v_opt"]).max() < 0.05
+
+
+def test_runopt_nlp_host_mirror():
+    """optSol = RunOpt_NLP(OPTsettings): the reference's field names and lengths (RunOpt_NLP.m:512-605); warm-started
+    from the saved forces the struct reproduces the saved one (objective 1e-6, E_opt(end) 1e-4 relative)."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import RunOpt_NLP
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    OPT["s_tv"] = s_tv
+    G = load_golden("abo_nlp")
+    forces = np.stack([G["Fm_opt"], np.minimum(G["Fb_opt"], -1e-3)], axis=1)
+    S = RunOpt_NLP(OPT, V, start_forces=forces, max_iter=60)
+    assert S["exitMessage"] == "Solve_Succeeded"
+    for k in ("s_opt", "v_opt", "theta_opt", "j_opt"):
+        assert S[k].shape == (871,)
+    for k in ("Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt", "P_opt", "E_opt", "a_opt", "Tm_opt", "rpm_opt",
+              "cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f"):
+        assert S[k].shape == (870,), k
+    np.testing.assert_allclose(S["s_velInc"], G["s_velInc"], atol=1e-9)
+    assert abs(S["E_opt"][-1] / G["E_opt"][-1] - 1) < 1e-4
+    assert abs(S["cost_xi_v"][-1] / G["cost_xi_v"][-1] - 1) < 1e-4
+    assert np.abs(S["v_opt"] - G["v_opt"]).max() < 0.05
+    # cold start on a short route
+    OPT2 = dict(OPT)
+    OPT2["t_sim"] = 30.0
+    S2 = RunOpt_NLP(OPT2, V, max_iter=80)
+    assert S2["exitMessage"] == "Solve_Succeeded" and S2["s_opt"].shape == (61,)
