@@ -720,16 +720,18 @@ k_nlp_rowdir(const NlpDev C, const double* __restrict__ blob, int B, const doubl
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Closed-loop nonlinear forward pass (include/eepacc_nlp.h: eepacc_nlp_rollout): u_k = u_base_k + alpha kf_k +
-// K_k (chi_k - chi_base_k), chi_{k+1} = f(chi_k, u_k) with the RK4 x 4 integrator.  Serial in k: one thread per route.
+// K_k (chi_k - chi_base_k), chi_{k+1} = f(chi_k, u_k) with the RK4 x 4 integrator.  Serial in k: one wavefront per route.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_nlp_rollout(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ alpha,
               const double* __restrict__ chi0, const double* __restrict__ u0, const double* __restrict__ work,
               double* __restrict__ chi1, double* __restrict__ u1) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wavefront per route: the stage's gains, base state and base controls stream global -> registers -> LDS one
+    // stage ahead (as in the Riccati sweep); lanes 0..5 form the controls, lane 0 integrates the interval
+    const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B) return;
     const eepacc_vehicle& V = C.V;
-    const double lmass = V.lambda * V.m, mg = V.m * V.g, za = V.zeta_a;
+    const double ilm = 1.0 / (V.lambda * V.m), mg = V.m * V.g, za = V.zeta_a;
     const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
     const double a = alpha ? alpha[r] : 0.0;
     const double* cb = chi0 + (size_t)r * (C.N + 1) * 4;
@@ -737,43 +739,56 @@ k_nlp_rollout(const NlpDev C, const double* __restrict__ blob, int B, const doub
     const double* wk = work ? work + (size_t)r * C.N * 50 : nullptr;
     double* cn = chi1 + (size_t)r * (C.N + 1) * 4;
     double* un = u1 + (size_t)r * C.N * 6;
-    double x[4] = {cb[0], cb[1], cb[2], cb[3]};
-    for (int i = 0; i < 4; ++i) cn[i] = x[i];
+    __shared__ double Kf[30], cbk[4], ubk[6], x[4], uu[6];
+    if (lane < 4) { x[lane] = cb[lane]; cn[lane] = cb[lane]; }
+    double f0 = 0.0, f1 = 0.0;
+    auto prefetch = [&](int k) {
+        if (lane < 30) f1 = wk ? wk[(size_t)k * 50 + lane] : 0.0;
+        if (lane >= 32 && lane < 36) f0 = cb[(size_t)k * 4 + lane - 32];
+        else if (lane >= 40 && lane < 46) f0 = ub[(size_t)k * 6 + lane - 40];
+    };
+    prefetch(0);
+    __syncthreads();
     for (int k = 0; k < C.N; ++k) {
-        double uu[6];
-        for (int i = 0; i < 6; ++i) {
-            double d = 0.0;
-            if (wk) {
-                const double* Kr = wk + (size_t)k * 50 + i * 5;
-                d = a * Kr[4];
-                for (int j2 = 0; j2 < 4; ++j2) d += Kr[j2] * (x[j2] - cb[(size_t)k * 4 + j2]);
+        if (lane < 30) Kf[lane] = f1;
+        if (lane >= 32 && lane < 36) cbk[lane - 32] = f0;
+        else if (lane >= 40 && lane < 46) ubk[lane - 40] = f0;
+        __syncthreads();
+        if (k + 1 < C.N) prefetch(k + 1);
+        if (lane < 6) {
+            const double* Kr = Kf + lane * 5;
+            const double d = a * Kr[4] + Kr[0] * (x[0] - cbk[0]) + Kr[1] * (x[1] - cbk[1]) + Kr[2] * (x[2] - cbk[2]) + Kr[3] * (x[3] - cbk[3]);
+            const double v = ubk[lane] + d;
+            uu[lane] = v;
+            un[(size_t)k * 6 + lane] = v;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const double F = uu[0] + uu[1];
+            double th = 0.0, sl;
+            if (!C.flat) pwa(t_slope, x[0], th, sl);
+            const double grav = V.c_r * mg * cos(th) + mg * sin(th);
+            double s = x[0], v = x[1];
+            const double DT = C.Ts / 4;
+            for (int m2 = 0; m2 < 4; ++m2) {
+                const double a1 = (F - za * v * v - grav) * ilm;
+                const double v2 = v + (DT / 2) * a1;
+                const double a2 = (F - za * v2 * v2 - grav) * ilm;
+                const double v3 = v + (DT / 2) * a2;
+                const double a3 = (F - za * v3 * v3 - grav) * ilm;
+                const double v4 = v + DT * a3;
+                const double a4 = (F - za * v4 * v4 - grav) * ilm;
+                s = s + (DT / 6) * (v + 2 * v2 + 2 * v3 + v4);
+                v = v + (DT / 6) * (a1 + 2 * a2 + 2 * a3 + a4);
             }
-            uu[i] = ub[(size_t)k * 6 + i] + d;
-            un[(size_t)k * 6 + i] = uu[i];
+            double th1 = 0.0;
+            if (!C.flat) pwa(t_slope, s, th1, sl);
+            const double p1 = (F - za * v * v - V.c_r * mg * cos(th1) - mg * sin(th1)) * ilm;
+            const double j1 = (p1 - x[2]) / C.Ts;
+            x[0] = s; x[1] = v; x[2] = p1; x[3] = j1;
         }
-        const double F = uu[0] + uu[1];
-        double th = 0.0, sl;
-        if (!C.flat) pwa(t_slope, x[0], th, sl);
-        const double grav = V.c_r * mg * cos(th) + mg * sin(th);
-        double s = x[0], v = x[1];
-        const double DT = C.Ts / 4;
-        for (int m2 = 0; m2 < 4; ++m2) {
-            const double a1 = (F - za * v * v - grav) / lmass;
-            const double v2 = v + (DT / 2) * a1;
-            const double a2 = (F - za * v2 * v2 - grav) / lmass;
-            const double v3 = v + (DT / 2) * a2;
-            const double a3 = (F - za * v3 * v3 - grav) / lmass;
-            const double v4 = v + DT * a3;
-            const double a4 = (F - za * v4 * v4 - grav) / lmass;
-            s = s + (DT / 6) * (v + 2 * v2 + 2 * v3 + v4);
-            v = v + (DT / 6) * (a1 + 2 * a2 + 2 * a3 + a4);
-        }
-        double th1 = 0.0;
-        if (!C.flat) pwa(t_slope, s, th1, sl);
-        const double p1 = (F - za * v * v - V.c_r * mg * cos(th1) - mg * sin(th1)) / lmass;
-        const double j1 = (p1 - x[2]) / C.Ts;
-        x[0] = s; x[1] = v; x[2] = p1; x[3] = j1;
-        for (int i = 0; i < 4; ++i) cn[(size_t)(k + 1) * 4 + i] = x[i];
+        __syncthreads();
+        if (lane < 4) cn[(size_t)(k + 1) * 4 + lane] = x[lane];
     }
 }
 
@@ -931,7 +946,7 @@ extern "C" int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alp
     if (!h || B < 1 || !chi_dev || !u_dev || !chi_new_dev || !u_new_dev || (work_dev && !alpha_dev))
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_rollout: null argument or B < 1");
     NLPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_nlp_rollout, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, alpha_dev, chi_dev, u_dev,
+    hipLaunchKernelGGL(k_nlp_rollout, dim3(B), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, alpha_dev, chi_dev, u_dev,
                        work_dev, chi_new_dev, u_new_dev);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;

@@ -526,6 +526,7 @@ class NlpSolver(NlpEvaluator):
             # line search accepts a step
             reg = reg_last.clone()
             accepted = ~active
+            skip = torch.zeros(B, dtype=torch.bool, device=dev)
             new_chi, new_u, new_t, new_cost, new_lam, new_nu = chi.clone(), u.clone(), t.clone(), cost.clone(), lam.clone(), nu.clone()
             ls_used = torch.zeros(B, dtype=torch.int32, device=dev)
             first = True
@@ -575,14 +576,23 @@ class NlpSolver(NlpEvaluator):
                 grow = need & ~acc_now
                 reg = torch.where(grow, torch.clamp(reg * 8.0, min=reg_first), reg)
                 lost = grow & (reg > reg_max)
-                status[lost] = 2
-                active = active & ~lost
-            moved = accepted & active
+                if bool(lost.any()):
+                    # no descent at any Levenberg term: the point is stationary for this barrier parameter up to a kink of
+                    # the lookups.  While the barrier can still fall, lower it and go on; at its floor the route stops
+                    cont = lost & (mu > mu_min)
+                    mu = torch.where(cont, torch.clamp(kappa_mu * mu, min=mu_min), mu)
+                    reg = torch.where(cont, torch.zeros_like(reg), reg)
+                    skip = skip | cont
+                    stop = lost & ~cont
+                    status[stop] = 2
+                    active = active & ~stop
+                    accepted = accepted | cont
+            moved = accepted & active & ~skip
             chi, u, t, cost, nu = new_chi, new_u, new_t, new_cost, new_nu
             lam = torch.where(b3(moved), torch.minimum(torch.maximum(new_lam, b3(mu) / (1e10 * t)), 1e10 * b3(mu) / t), lam)
             _, r = self._values(s_tv, s_tv_bm, chi, u, sigma)             # rows of the point every route now stands at
             reg_last = torch.where(moved, torch.where(ls_used <= 1, reg / 3.0, reg), reg_last)
-            reg_last = torch.where(reg_last < reg_first, torch.zeros_like(reg_last), reg_last)
+            reg_last = torch.where((reg_last < reg_first) | skip, torch.zeros_like(reg_last), reg_last)
         return dict(chi=chi, u=u, J=cost / sigma, status=status, iters=iters, kkt=kkt, lam=lam, t=t)
 
 
