@@ -548,8 +548,8 @@ class NlpSolver(NlpEvaluator):
                 a_p = torch.clamp(torch.where(dt < 0, -b3(tau) * t / torch.where(dt < 0, dt, -torch.ones_like(dt)), big).amin(dim=(1, 2)), max=1.0)
                 a_d = torch.clamp(torch.where(dlam < 0, -b3(tau) * lam / torch.where(dlam < 0, dlam, -torch.ones_like(dlam)), big).amin(dim=(1, 2)), max=1.0)
                 infeas = (rg * rows_i).sum(dim=(1, 2))
-                lam_i = (lam_new.abs() * rows_i).amax(dim=(1, 2))
-                rho = torch.where(infeas > 0, torch.maximum(rho, 1.1 * lam_i), rho)
+                lam_i = torch.nan_to_num((lam_new.abs() * rows_i).amax(dim=(1, 2)), nan=0.0, posinf=0.0)
+                rho = torch.where((infeas > 0) & ok & need, torch.maximum(rho, 1.1 * lam_i), rho)   # only from a valid factorisation
                 phi0 = cost - mu * torch.log(t).sum(dim=(1, 2)) + rho * infeas
                 a = a_p.clone()
                 acc_now = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -588,6 +588,9 @@ class NlpSolver(NlpEvaluator):
                     active = active & ~stop
                     accepted = accepted | cont
             moved = accepted & active & ~skip
+            if verbose:
+                print("      reg %s a_p %s alpha %s a_d %s infeas %s rho %s ls %s moved %s" % (reg[:2].tolist(), a_p[:2].tolist(), a[:2].tolist(),
+                      a_d[:2].tolist(), infeas[:2].tolist(), rho[:2].tolist(), ls_used[:2].tolist(), moved[:2].tolist()), flush=True)
             chi, u, t, cost, nu = new_chi, new_u, new_t, new_cost, new_nu
             lam = torch.where(b3(moved), torch.minimum(torch.maximum(new_lam, b3(mu) / (1e10 * t)), 1e10 * b3(mu) / t), lam)
             _, r = self._values(s_tv, s_tv_bm, chi, u, sigma)             # rows of the point every route now stands at
