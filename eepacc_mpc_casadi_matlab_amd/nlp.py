@@ -509,8 +509,8 @@ class NlpSolver(NlpEvaluator):
                 e_compm = (lt - b3(mu)).abs().amax(dim=(1, 2))
                 err0 = torch.maximum(torch.maximum(e_dual, e_prim), e_comp0)
                 done = active & (err0 <= tol)
-                kkt[active] = torch.stack([e_dual, e_prim, e_comp0], dim=1)[active]
-                status[done] = 0
+                kkt = torch.where(active[:, None], torch.stack([e_dual, e_prim, e_comp0], dim=1), kkt)
+                status = torch.where(done, torch.zeros_like(status), status)
                 active = active & ~done
                 dec = active & (mu > mu_min) & (torch.maximum(torch.maximum(e_dual, e_prim), e_compm) <= kappa_eps * mu)
                 if not bool(dec.any()):
@@ -527,7 +527,7 @@ class NlpSolver(NlpEvaluator):
             reg = reg_last.clone()
             accepted = ~active
             skip = torch.zeros(B, dtype=torch.bool, device=dev)
-            new_chi, new_u, new_t, new_cost, new_lam, new_nu = chi.clone(), u.clone(), t.clone(), cost.clone(), lam.clone(), nu.clone()
+            new_chi, new_u, new_t, new_cost, new_lam, new_nu = chi, u, t, cost, lam, nu
             ls_used = torch.zeros(B, dtype=torch.int32, device=dev)
             first = True
             for _attempt in range(40):
@@ -564,12 +564,12 @@ class NlpSolver(NlpEvaluator):
                     inf_t = ((r_t + t_t) * rows_i).sum(dim=(1, 2))
                     phi_t = cost_t - mu * torch.log(torch.clamp(t_t, min=1e-300)).sum(dim=(1, 2)) + rho * inf_t
                     good = trial & feas & (phi_t <= phi0 + 1e-13 * phi0.abs())
-                    if bool(good.any()):
-                        new_chi[good], new_u[good], new_t[good], new_cost[good] = chi_t[good], u_t[good], t_t[good], cost_t[good]
-                        lam_g = lam + b3(a_d) * dlam
-                        new_lam[good] = lam_g[good]
-                        new_nu[good] = nu_new[good]
-                        ls_used[good] = ls
+                    g3 = b3(good)                                   # masked selects, no host round trip
+                    new_chi, new_u, new_t = torch.where(g3, chi_t, new_chi), torch.where(g3, u_t, new_u), torch.where(g3, t_t, new_t)
+                    new_cost = torch.where(good, cost_t, new_cost)
+                    new_lam = torch.where(g3, lam + b3(a_d) * dlam, new_lam)
+                    new_nu = torch.where(g3, nu_new, new_nu)
+                    ls_used = torch.where(good, torch.full_like(ls_used, ls), ls_used)
                     acc_now = acc_now | good
                     a = torch.where(trial & ~good, 0.5 * a, a)
                 accepted = accepted | acc_now
@@ -584,7 +584,7 @@ class NlpSolver(NlpEvaluator):
                     reg = torch.where(cont, torch.zeros_like(reg), reg)
                     skip = skip | cont
                     stop = lost & ~cont
-                    status[stop] = 2
+                    status = torch.where(stop, torch.full_like(status, 2), status)
                     active = active & ~stop
                     accepted = accepted | cont
             moved = accepted & active & ~skip
