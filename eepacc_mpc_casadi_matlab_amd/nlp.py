@@ -470,7 +470,8 @@ class NlpSolver(NlpEvaluator):
         return chi, u
 
     def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
-              reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False):
+              reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False,
+              until_first=False):
         """s_tv [B][N], chi [B][N+1][4], u [B][N][6] (a start whose states are the rollout of its controls).
         Returns dict(chi, u, J [B], status [B] (0 KKT point to `tol`, 1 iteration limit, 2 Levenberg limit), iters [B],
         kkt [B][3], lam, t)."""
@@ -519,8 +520,8 @@ class NlpSolver(NlpEvaluator):
             if verbose:
                 print("it %3d active %d  J %s  mu %s  dual %s" % (it, int(active.sum()), (cost[:3] / sigma).tolist(), mu[:3].tolist(),
                                                                    e_dual[:3].tolist()), flush=True)
-            if not bool(active.any()):
-                break
+            if not bool(active.any()) or (until_first and bool((status == 0).any())):
+                break                                       # until_first: the batch holds several starts of ONE problem
             iters += active.to(torch.int32)
             # Levenberg loop: the regularisation of a route grows until its factorisation has the right inertia and the
             # line search accepts a step
@@ -599,10 +600,12 @@ class NlpSolver(NlpEvaluator):
         return dict(chi=chi, u=u, J=cost / sigma, status=status, iters=iters, kkt=kkt, lam=lam, t=t)
 
 
-def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables: Dict[str, Any], s_tv) -> np.ndarray:
+def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables: Dict[str, Any], s_tv, lookahead: int = 0,
+                        tau: float = 2.0) -> np.ndarray:
     """Force trajectory [N][2] of a plain car-following rollout (speed target = min(speed limit - 1, stop profile,
     desired-headway speed behind the lead vehicle), acceleration (target - v)/2 s clipped to [-2, 1.2] m/s^2): the start
-    the solver is given where the reference starts IPOPT from z0 = 0 (RunOpt_NLP.m:348)."""
+    the solver is given where the reference starts IPOPT from z0 = 0 (RunOpt_NLP.m:348).  `lookahead` > 0 (samples) caps the
+    target by the steady speed that reaches the lead vehicle's position that far ahead: a smooth cruise instead of stop and go."""
     N, Ts = int(tables["N"]), float(OPTsettings["Ts"])
     lm = V["lambda"] * V["m"]
     mg = V["m"] * V["g"]
@@ -617,7 +620,10 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
         stop = float(pwa(s + 2.0 * v, *tables["stop"])[0])
         gap = float(s_tv[min(k + 1, N - 1)]) - 2.0 - 1.0 - s
         vt = max(0.0, min(vlim - 1.0, stop - 0.5, max(0.0, gap / 3.0)))
-        a = min(1.2, max(-2.0, (vt - v) / 2.0))
+        if lookahead > 0:                                   # steady speed towards where the lead vehicle will be
+            kl = min(k + lookahead, N - 1)
+            vt = min(vt, max(0.0, (float(s_tv[kl]) - 3.0 - s) / ((kl - k) * Ts + 3.0)))
+        a = min(1.2, max(-2.0, (vt - v) / tau))
         if v + a * Ts < 0.0:
             a = -v / Ts
         F = lm * a + V["zeta_a"] * v * v + grav
@@ -640,13 +646,20 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
 
 
 def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,
-               max_iter: int = 300, mu_init: float | None = None) -> Dict[str, Any]:
+               max_iter: int = 1500, mu_init: float | None = None,
+               starts=((120, 8.0), (200, 2.0), (120, 2.0), (60, 8.0), (450, 8.0), (200, 8.0), (60, 2.0), (0, 2.0))) -> Dict[str, Any]:
     """`optSol = RunOpt_NLP(OPTsettings)` (ABO/RunOpt_NLP.m, called from ABO/Main.m:124): same fields as the reference's
-    struct.  `OPTsettings["s_tv"]` is the lead trace of Main.m:88.  The start is the car-following rollout unless
-    `start_forces` [N][2] (Fm, Fb) is given; `exitMessage` is 'Solve_Succeeded' for a KKT point, otherwise
-    'Maximum_Iterations_Exceeded' / 'Restoration_Failed' (IPOPT's names for the two other outcomes) -- see DESIGN.md
-    section 7 for where the iteration converges."""
+    struct.  `OPTsettings["s_tv"]` is the lead trace of Main.m:88.
+
+    The problem has many local solutions of nearly equal objective (a stop-and-go trajectory behind the lead vehicle is
+    0.5 % above the smooth cruise IPOPT finds from z0 = 0), and the iteration has no restoration phase, so the cold start is
+    a **multi-start in one batch**: car-following rollouts with different look-ahead horizons / response times
+    (`starts` = (look-ahead samples, time constant); look-ahead 0 = plain car following) run side by side until the first
+    reaches a KKT point; if none does, the lowest objective is returned with `exitMessage`
+    'Maximum_Iterations_Exceeded' / 'Restoration_Failed' (IPOPT's names for those outcomes).  `start_forces` [N][2]
+    (Fm, Fb) replaces the multi-start by one warm start."""
     import time
+    import torch
     from .settings import SetVehicleParameters
     V = V or SetVehicleParameters(OPTsettings.get("tree", "ABO"))
     sol = NlpSolver(OPTsettings, V, device=device)
@@ -656,18 +669,28 @@ def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, d
     th0 = 0.0 if sol.tables["flat"] else float(pwa(s0, *sol.tables["slope"])[0])
     p0 = -(V["zeta_a"] * v0 * v0 + V["c_r"] * V["m"] * V["g"] * math.cos(th0) + V["m"] * V["g"] * math.sin(th0)) / (V["lambda"] * V["m"])
     warm = start_forces is not None
-    forces = np.asarray(start_forces, float) if warm else car_following_start(OPTsettings, V, sol.tables, s_tv)
-    chi, u = sol.start_from_controls(s_tv[None], np.array([[s0, v0, p0, 0.0]]), forces[None], margin=1e-3 if warm else 1.0)
+    if warm:
+        forces = np.asarray(start_forces, float)[None]
+    else:
+        forces = np.stack([car_following_start(OPTsettings, V, sol.tables, s_tv, lookahead=min(int(L), N - 1), tau=float(tc))
+                           for (L, tc) in starts])
+    B = forces.shape[0]
+    stv = np.tile(s_tv[None], (B, 1))
+    chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (B, 1)), forces, margin=1e-3 if warm else 1.0)
     t0 = time.perf_counter()
-    R = sol.solve(s_tv[None], chi, u, max_iter=max_iter, mu_init=(1e-4 if warm else 1.0) if mu_init is None else mu_init)
+    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=(1e-4 if warm else 1.0) if mu_init is None else mu_init,
+                  until_first=not warm)
     sol.synchronize()
     tSolve = time.perf_counter() - t0
-    chi, u = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy()
+    st, Jb = R["status"].cpu().numpy(), R["J"].cpu().numpy()
+    conv = np.nonzero(st == 0)[0]
+    i = int(conv[np.argmin(Jb[conv])]) if len(conv) else int(np.argmin(Jb))
+    chi, u = R["chi"][i].cpu().numpy(), R["u"][i].cpu().numpy()
     theta = np.zeros(N + 1) if sol.tables["flat"] else pwa(chi[:, 0], *sol.tables["slope"])[0]
     out = dict(s_velInc=sol.tables["vinc"][0], v_velInc=sol.tables["vinc"][1], tSolve=tSolve,
-               exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(R["status"][0])],
+               exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(st[i])],
                s_opt=chi[:, 0], v_opt=chi[:, 1], theta_opt=theta, j_opt=chi[:, 3], Fm_opt=u[:, 0], Fb_opt=u[:, 1],
                xi_v_opt=u[:, 2], xi_h_opt=u[:, 3], xi_s_opt=u[:, 4], xi_f_opt=u[:, 5],
-               J=float(R["J"][0]), iterations=int(R["iters"][0]))
+               J=float(Jb[i]), iterations=int(R["iters"][i]), start_index=i, starts_J=Jb.tolist(), starts_status=st.tolist())
     out.update(postprocess(OPTsettings, V, chi[:, 1], u[:, 0], chi[:, 3], u[:, 2:]))
     return out

@@ -347,3 +347,26 @@ def test_runopt_nlp_host_mirror():
     OPT2["t_sim"] = 30.0
     S2 = RunOpt_NLP(OPT2, V, max_iter=80)
     assert S2["exitMessage"] == "Solve_Succeeded" and S2["s_opt"].shape == (61,)
+
+
+@pytest.mark.parametrize("tree,name", [("ABO", "abo_nlp"), ("ORIG", "orig_nlp")])
+def test_runopt_nlp_cold_start_reaches_the_saved_solution(tree, name):
+    """Objective-level parity with the reference from a COLD start (config 5's problem, the reference's own scenario):
+    RunOpt_NLP's multi-start batch (car-following rollouts with different look-ahead horizons; nothing of the saved
+    solution is used) reaches a KKT point whose objective equals that of the saved IPOPT solution to 1e-6 relative and
+    whose speed trajectory is the saved one to 0.05 m/s."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import RunOpt_NLP
+    OPT, V, s_tv, _ = make_case(tree=tree)
+    OPT["s_tv"] = s_tv
+    G = load_golden(name)
+    P = M.NlpProblem(OPT, V, s_tv)
+    U = np.stack([G[k] for k in ("Fm_opt", "Fb_opt", "xi_v_opt", "xi_h_opt", "xi_s_opt", "xi_f_opt")], axis=1)
+    J_saved = P.eval_reference_form(G["s_opt"], G["v_opt"], G["theta_opt"], G["j_opt"], U)["J"]
+    S = RunOpt_NLP(OPT, V)
+    assert S["exitMessage"] == "Solve_Succeeded", (S["exitMessage"], S["starts_status"], [j / J_saved - 1 for j in S["starts_J"]])
+    assert abs(S["J"] / J_saved - 1) < 1e-6, S["J"] / J_saved - 1
+    assert np.abs(S["v_opt"] - G["v_opt"]).max() < 0.05
+    assert np.abs(S["s_opt"] - G["s_opt"]).max() < 0.5
+    assert abs(S["E_opt"][-1] / G["E_opt"][-1] - 1) < 1e-4
+    print("RunOpt_NLP cold start (%s): J/J_saved - 1 = %.2e, %d iterations, %.1f s, start %d" %
+          (tree, S["J"] / J_saved - 1, S["iterations"], S["tSolve"], S["start_index"]))
