@@ -76,9 +76,10 @@ def profile_figures(fb: bool, N: int):
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["abmpc", "fbmpc", "blmpc"], default="abmpc",
+    ap.add_argument("--workload", choices=["abmpc", "fbmpc", "blmpc", "nlp"], default="abmpc",
                     help="abmpc: the headline (BASELINE.json configs[1]); fbmpc: configs[2]; blmpc: the baseline controller "
-                         "(RunOpt_BLMPC, a handle with bl_mode = 1); same contract")
+                         "(RunOpt_BLMPC, a handle with bl_mode = 1); same contract; nlp: BASELINE configs[4] -- RunOpt_NLP, "
+                         "--batch routes per GPU (default there: 128 = 1024 / 8), one step = one cold-start solve of all of them")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096)
@@ -274,10 +275,70 @@ def run_bench(args, make_engine=None, device=None, backend=None):
     return res
 
 
+def run_nlp_bench(args):
+    """BASELINE configs[4]: RunOpt_NLP for `--batch` routes per GPU (the reference's 435 s scenario with the lead vehicle's
+    speed trace scaled per route), each solved from a cold start by the multi-start batch of nlp.solve_routes.  Routes shard
+    across ranks with no data-path collective; one all-reduce (SUM) of (routes at a KKT point, sum of objectives) at the end."""
+    import torch
+    import torch.distributed as dist
+    from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver, solve_routes
+    from eepacc_mpc_casadi_matlab_amd.settings import Run_DrivingCycle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import make_case
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    K = args.steps if args.steps != 200 else 1
+    W = args.warmup if args.warmup != 200 else 0
+    Rn = args.batch if args.batch != 4096 else 128
+    OPT, V, _, _ = make_case("ABO")
+    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
+    rng = np.random.default_rng(100 + rank)
+    traces = []
+    for f in rng.uniform(0.9, 1.1, Rn):                                   # per-route lead vehicle: the cycle's speeds scaled
+        s_tv, _ = Run_DrivingCycle(OPT, V_TO_resampled=lead["V_TO_2Hz"] * f)
+        traces.append(s_tv - OPT["TVlength"])
+    traces = np.stack(traces)
+    sol = NlpSolver(OPT, V, device=local)
+    starts = ((120, 8.0), (200, 2.0), (120, 2.0), (60, 8.0), (450, 8.0), (200, 8.0), (60, 2.0), (0, 2.0))
+    for _ in range(W):
+        solve_routes(sol, OPT, V, traces, starts, max_iter=800)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        R = solve_routes(sol, OPT, V, traces, starts, max_iter=800)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    kp = torch.stack([(R["status"] == 0).sum().double(), R["J"].sum(), R["iters"].double().sum()])
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    total = world * Rn * K
+    return {"metric": "RunOpt_NLP routes solved/s (whole node), 435 s route = 870 intervals, cold start", "value": total / float(dt),
+            "unit": "routes/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": float(dt) * 1e3 / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "RunOpt_NLP, %d routes per GPU x %d starts, 870 intervals, lead trace scaled per route" % (Rn, len(starts)),
+                       "routes_per_gpu": Rn, "starts_per_route": len(starts)},
+            "solver": {"routes_at_kkt_point": int(kp[0].item()), "routes": world * Rn, "mean_iterations": float(kp[2].item()) / (world * Rn),
+                       "sum_objective": float(kp[1].item())},
+            "reference": {"ipopt_tSolve_s_one_route": 190.4754463, "source": "ABO/savedNLPsol.mat (NLPsol.tSolve), other hardware"}}
+
+
 def main():
     args = build_parser().parse_args()
     import torch.distributed as dist
-    res = run_bench(args)
+    res = run_nlp_bench(args) if args.workload == "nlp" else run_bench(args)
     if res is not None:
         print(json.dumps(res))
     if dist.is_initialized():

@@ -471,7 +471,7 @@ class NlpSolver(NlpEvaluator):
 
     def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
               reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False,
-              until_first=False):
+              until_first=False, groups=None):
         """s_tv [B][N], chi [B][N+1][4], u [B][N][6] (a start whose states are the rollout of its controls).
         Returns dict(chi, u, J [B], status [B] (0 KKT point to `tol`, 1 iteration limit, 2 Levenberg limit), iters [B],
         kkt [B][3], lam, t)."""
@@ -496,6 +496,11 @@ class NlpSolver(NlpEvaluator):
         kkt = torch.zeros((B, 3), dtype=f64, device=dev)
         inf = torch.full((B,), float("inf"), dtype=f64, device=dev)
         b3 = lambda x: x[:, None, None]
+        if until_first and groups is None:
+            groups = torch.zeros(B, dtype=torch.int64, device=dev)
+        if groups is not None:                              # starts of one problem share a group: the first KKT point ends it
+            groups = torch.as_tensor(groups, dtype=torch.int64, device=dev)
+            n_groups = int(groups.max().item()) + 1
         for it in range(max_iter):
             # Newton system at the current point; the barrier parameter falls while its subproblem is solved
             for _ in range(8):
@@ -520,8 +525,11 @@ class NlpSolver(NlpEvaluator):
             if verbose:
                 print("it %3d active %d  J %s  mu %s  dual %s" % (it, int(active.sum()), (cost[:3] / sigma).tolist(), mu[:3].tolist(),
                                                                    e_dual[:3].tolist()), flush=True)
-            if not bool(active.any()) or (until_first and bool((status == 0).any())):
-                break                                       # until_first: the batch holds several starts of ONE problem
+            if groups is not None:
+                gdone = torch.zeros(n_groups, dtype=torch.int32, device=dev).scatter_reduce(0, groups, (status == 0).to(torch.int32), "amax")
+                active = active & ~(gdone[groups] > 0)
+            if not bool(active.any()):
+                break
             iters += active.to(torch.int32)
             # Levenberg loop: the regularisation of a route grows until its factorisation has the right inertia and the
             # line search accepts a step
@@ -600,36 +608,45 @@ class NlpSolver(NlpEvaluator):
         return dict(chi=chi, u=u, J=cost / sigma, status=status, iters=iters, kkt=kkt, lam=lam, t=t)
 
 
-def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables: Dict[str, Any], s_tv, lookahead: int = 0,
-                        tau: float = 2.0) -> np.ndarray:
-    """Force trajectory [N][2] of a plain car-following rollout (speed target = min(speed limit - 1, stop profile,
-    desired-headway speed behind the lead vehicle), acceleration (target - v)/2 s clipped to [-2, 1.2] m/s^2): the start
-    the solver is given where the reference starts IPOPT from z0 = 0 (RunOpt_NLP.m:348).  `lookahead` > 0 (samples) caps the
-    target by the steady speed that reaches the lead vehicle's position that far ahead: a smooth cruise instead of stop and go."""
+def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables: Dict[str, Any], s_tv, lookahead=0,
+                        tau=2.0) -> np.ndarray:
+    """Force trajectory [N][2] (or [M][N][2] for M lead traces s_tv [M][N] with per-trace `lookahead` / `tau`) of a plain
+    car-following rollout: speed target = min(speed limit - 1, stop profile, desired-headway speed behind the lead
+    vehicle), acceleration (target - v)/tau clipped to [-2, 1.2] m/s^2 -- the start the solver is given where the reference
+    starts IPOPT from z0 = 0 (RunOpt_NLP.m:348).  `lookahead` > 0 (samples) caps the target by the steady speed that
+    reaches the lead vehicle's position that far ahead: a smooth cruise instead of stop and go."""
+    s_tv = np.asarray(s_tv, dtype=np.float64)
+    single = s_tv.ndim == 1
+    stv = s_tv[None] if single else s_tv
+    M_ = stv.shape[0]
+    la = np.broadcast_to(np.asarray(lookahead, dtype=np.int64), (M_,))
+    tc = np.broadcast_to(np.asarray(tau, dtype=np.float64), (M_,))
     N, Ts = int(tables["N"]), float(OPTsettings["Ts"])
     lm = V["lambda"] * V["m"]
     mg = V["m"] * V["g"]
     Fm_min = -V["phi"] * V["T_m_max"] / V["eta_TF"]
-    s, v = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
-    out = np.zeros((N, 2))
+    s = np.full(M_, float(OPTsettings["s_init"]))
+    v = np.full(M_, float(OPTsettings["v_init"]))
+    out = np.zeros((M_, N, 2))
     flat = tables["flat"]
+    rows = np.arange(M_)
     for k in range(N):
-        th = 0.0 if flat else float(pwa(s, *tables["slope"])[0])
-        grav = V["c_r"] * mg * math.cos(th) + mg * math.sin(th)
-        vlim = float(pwa(s + 2.0 * v, *tables["vlim"])[0])
-        stop = float(pwa(s + 2.0 * v, *tables["stop"])[0])
-        gap = float(s_tv[min(k + 1, N - 1)]) - 2.0 - 1.0 - s
-        vt = max(0.0, min(vlim - 1.0, stop - 0.5, max(0.0, gap / 3.0)))
-        if lookahead > 0:                                   # steady speed towards where the lead vehicle will be
-            kl = min(k + lookahead, N - 1)
-            vt = min(vt, max(0.0, (float(s_tv[kl]) - 3.0 - s) / ((kl - k) * Ts + 3.0)))
-        a = min(1.2, max(-2.0, (vt - v) / tau))
-        if v + a * Ts < 0.0:
-            a = -v / Ts
+        th = np.zeros(M_) if flat else pwa(s, *tables["slope"])[0]
+        grav = V["c_r"] * mg * np.cos(th) + mg * np.sin(th)
+        vlim = pwa(s + 2.0 * v, *tables["vlim"])[0]
+        stop = pwa(s + 2.0 * v, *tables["stop"])[0]
+        gap = stv[:, min(k + 1, N - 1)] - 2.0 - 1.0 - s
+        vt = np.maximum(0.0, np.minimum(np.minimum(vlim - 1.0, stop - 0.5), np.maximum(0.0, gap / 3.0)))
+        kl = np.minimum(k + la, N - 1)
+        ahead = np.maximum(0.0, (stv[rows, kl] - 3.0 - s) / ((kl - k) * Ts + 3.0))
+        vt = np.where(la > 0, np.minimum(vt, ahead), vt)
+        a = np.minimum(1.2, np.maximum(-2.0, (vt - v) / tc))
+        a = np.where(v + a * Ts < 0.0, -v / Ts, a)
         F = lm * a + V["zeta_a"] * v * v + grav
-        Fm, Fb = (F, -1.0) if F > Fm_min * 0.5 else (Fm_min * 0.5, F - Fm_min * 0.5)
-        Fm += 1.0
-        out[k] = (Fm, Fb)
+        big = F > Fm_min * 0.5
+        Fm = np.where(big, F, Fm_min * 0.5) + 1.0
+        Fb = np.where(big, -1.0, F - Fm_min * 0.5)
+        out[:, k, 0], out[:, k, 1] = Fm, Fb
         Ft = Fm + Fb
         DT = Ts / 4
         for _ in range(4):                                  # the interval's RK4 x 4 (RunOpt_NLP.m:262-278)
@@ -640,9 +657,34 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
             a3 = (Ft - V["zeta_a"] * v3 * v3 - grav) / lm
             v4 = v + DT * a3
             a4 = (Ft - V["zeta_a"] * v4 * v4 - grav) / lm
-            s += DT / 6 * (v + 2 * v2 + 2 * v3 + v4)
-            v += DT / 6 * (a1 + 2 * a2 + 2 * a3 + a4)
-    return out
+            s = s + DT / 6 * (v + 2 * v2 + 2 * v3 + v4)
+            v = v + DT / 6 * (a1 + 2 * a2 + 2 * a3 + a4)
+    return out[0] if single else out
+
+
+def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500):
+    """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
+    gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch.  Returns
+    per route: J, status, iterations, index of the winning start, chi [R][N+1][4], u [R][N][6]."""
+    import torch
+    N = sol.N
+    s_tv_routes = np.asarray(s_tv_routes, dtype=np.float64)[:, :N]
+    Rn, S = s_tv_routes.shape[0], len(starts)
+    s0, v0 = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
+    th0 = 0.0 if sol.tables["flat"] else float(pwa(s0, *sol.tables["slope"])[0])
+    p0 = -(V["zeta_a"] * v0 * v0 + V["c_r"] * V["m"] * V["g"] * math.cos(th0) + V["m"] * V["g"] * math.sin(th0)) / (V["lambda"] * V["m"])
+    stv = np.repeat(s_tv_routes, S, axis=0)
+    forces = car_following_start(OPTsettings, V, sol.tables, stv, lookahead=np.tile([min(int(L), N - 1) for (L, _) in starts], Rn),
+                                 tau=np.tile([float(tc) for (_, tc) in starts], Rn))
+    groups = np.repeat(np.arange(Rn), S)
+    chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1)), forces, margin=1.0)
+    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups)
+    st = R["status"].view(Rn, S)
+    J = torch.where(st == 0, R["J"].view(Rn, S), R["J"].view(Rn, S) + 1e30)       # a KKT point beats any unfinished start
+    win = J.argmin(dim=1)
+    idx = torch.arange(Rn, device=win.device) * S + win
+    return dict(J=R["J"][idx], status=R["status"][idx], iters=R["iters"][idx], start=win, chi=R["chi"][idx], u=R["u"][idx],
+                all_J=R["J"].view(Rn, S), all_status=st)
 
 
 def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,
@@ -669,28 +711,24 @@ def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, d
     th0 = 0.0 if sol.tables["flat"] else float(pwa(s0, *sol.tables["slope"])[0])
     p0 = -(V["zeta_a"] * v0 * v0 + V["c_r"] * V["m"] * V["g"] * math.cos(th0) + V["m"] * V["g"] * math.sin(th0)) / (V["lambda"] * V["m"])
     warm = start_forces is not None
+    t0 = time.perf_counter()
     if warm:
         forces = np.asarray(start_forces, float)[None]
+        chi, u = sol.start_from_controls(s_tv[None], np.array([[s0, v0, p0, 0.0]]), forces, margin=1e-3)
+        R = sol.solve(s_tv[None], chi, u, max_iter=max_iter, mu_init=1e-4 if mu_init is None else mu_init)
+        st, Jb, i = R["status"].cpu().numpy(), R["J"].cpu().numpy(), 0
+        chi, u, n_it = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy(), int(R["iters"][0])
     else:
-        forces = np.stack([car_following_start(OPTsettings, V, sol.tables, s_tv, lookahead=min(int(L), N - 1), tau=float(tc))
-                           for (L, tc) in starts])
-    B = forces.shape[0]
-    stv = np.tile(s_tv[None], (B, 1))
-    chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (B, 1)), forces, margin=1e-3 if warm else 1.0)
-    t0 = time.perf_counter()
-    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=(1e-4 if warm else 1.0) if mu_init is None else mu_init,
-                  until_first=not warm)
+        R = solve_routes(sol, OPTsettings, V, s_tv[None], starts, max_iter=max_iter)
+        st, Jb, i = R["all_status"][0].cpu().numpy(), R["all_J"][0].cpu().numpy(), int(R["start"][0])
+        chi, u, n_it = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy(), int(R["iters"][0])
     sol.synchronize()
     tSolve = time.perf_counter() - t0
-    st, Jb = R["status"].cpu().numpy(), R["J"].cpu().numpy()
-    conv = np.nonzero(st == 0)[0]
-    i = int(conv[np.argmin(Jb[conv])]) if len(conv) else int(np.argmin(Jb))
-    chi, u = R["chi"][i].cpu().numpy(), R["u"][i].cpu().numpy()
     theta = np.zeros(N + 1) if sol.tables["flat"] else pwa(chi[:, 0], *sol.tables["slope"])[0]
     out = dict(s_velInc=sol.tables["vinc"][0], v_velInc=sol.tables["vinc"][1], tSolve=tSolve,
                exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(st[i])],
                s_opt=chi[:, 0], v_opt=chi[:, 1], theta_opt=theta, j_opt=chi[:, 3], Fm_opt=u[:, 0], Fb_opt=u[:, 1],
                xi_v_opt=u[:, 2], xi_h_opt=u[:, 3], xi_s_opt=u[:, 4], xi_f_opt=u[:, 5],
-               J=float(Jb[i]), iterations=int(R["iters"][i]), start_index=i, starts_J=Jb.tolist(), starts_status=st.tolist())
+               J=float(Jb[i]), iterations=n_it, start_index=i, starts_J=Jb.tolist(), starts_status=st.tolist())
     out.update(postprocess(OPTsettings, V, chi[:, 1], u[:, 0], chi[:, 3], u[:, 2:]))
     return out
