@@ -303,16 +303,16 @@ def run_nlp_bench(args):
         traces.append(s_tv - OPT["TVlength"])
     traces = np.stack(traces)
     sol = NlpSolver(OPT, V, device=local)
-    starts = ((120, 8.0), (200, 2.0), (120, 2.0), (60, 8.0), (450, 8.0), (200, 8.0), (60, 2.0), (0, 2.0))
+    starts = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
     for _ in range(W):
-        solve_routes(sol, OPT, V, traces, starts, max_iter=800)
+        solve_routes(sol, OPT, V, traces, starts, max_iter=600)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        R = solve_routes(sol, OPT, V, traces, starts, max_iter=800)
+        R = solve_routes(sol, OPT, V, traces, starts, max_iter=600)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

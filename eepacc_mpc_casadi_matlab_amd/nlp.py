@@ -689,14 +689,14 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
 
 def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,
                max_iter: int = 1500, mu_init: float | None = None,
-               starts=((120, 8.0), (200, 2.0), (120, 2.0), (60, 8.0), (450, 8.0), (200, 8.0), (60, 2.0), (0, 2.0))) -> Dict[str, Any]:
+               starts=((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))) -> Dict[str, Any]:
     """`optSol = RunOpt_NLP(OPTsettings)` (ABO/RunOpt_NLP.m, called from ABO/Main.m:124): same fields as the reference's
     struct.  `OPTsettings["s_tv"]` is the lead trace of Main.m:88.
 
     The problem has many local solutions of nearly equal objective (a stop-and-go trajectory behind the lead vehicle is
     0.5 % above the smooth cruise IPOPT finds from z0 = 0), and the iteration has no restoration phase, so the cold start is
     a **multi-start in one batch**: car-following rollouts with different look-ahead horizons / response times
-    (`starts` = (look-ahead samples, time constant); look-ahead 0 = plain car following) run side by side until the first
+    (`starts` = (look-ahead samples, time constant); chosen from the survey profiles/r02_nlp_start_survey.json) run side by side until the first
     reaches a KKT point; if none does, the lowest objective is returned with `exitMessage`
     'Maximum_Iterations_Exceeded' / 'Restoration_Failed' (IPOPT's names for those outcomes).  `start_forces` [N][2]
     (Fm, Fb) replaces the multi-start by one warm start."""
