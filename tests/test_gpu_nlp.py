@@ -1,8 +1,13 @@
-"""GPU parity of the RunOpt_NLP function evaluator (include/eepacc_nlp.h) against the numpy oracle
-(oracle/nlp_oracle.py), through the C-ABI: objective, equality rows, every inequality row, the objective
-gradient and the integrator's Jacobian blocks.  fp64; tolerances: 1e-12 relative on J, 1e-9 absolute on rows
-(values up to 1e5), 1e-9 relative on derivatives (checked against the oracle's jets and against central
-differences of the kernel's own values)."""
+"""GPU parity of RunOpt_NLP (include/eepacc_nlp.h, eepacc_mpc_casadi_matlab_amd/nlp.py) against the numpy oracle
+(oracle/nlp_oracle.py) and the reference's saved IPOPT solutions, through the C-ABI:
+
+* function evaluator: objective, equality rows, every inequality row, objective gradient, integrator Jacobian blocks
+  (fp64; 1e-12 relative on J, 1e-9 absolute on rows of magnitude up to 1e5, 1e-9 relative on derivatives, also checked
+  against central differences of the kernel's own values);
+* Newton-system assembly, Riccati sweep and their product (operator-level parity 1e-10 / 1e-9 / 1e-7);
+* the batched interior-point solver: short routes against the oracle solver, batch = singles, the full route from the
+  saved controls and -- the objective-level parity bar of SURVEY.md section 8f -- from a COLD start for both trees
+  (objective within 1e-6 relative of the saved IPOPT solution's, speeds within 0.05 m/s)."""
 import numpy as np
 import pytest
 
