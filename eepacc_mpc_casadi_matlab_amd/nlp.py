@@ -5,9 +5,10 @@
 * ``NlpEvaluator`` -- front-end of include/eepacc_nlp.h: objective, constraint rows, objective gradient and the
   integrator's Jacobian blocks of the multiple-shooting NLP for a batch of routes on the GPU (what IPOPT calls back
   into every iteration, RunOpt_NLP.m:505-510).  There is no CPU path: without the HIP library or a GPU it raises.
+* ``NlpSolver`` / ``solve_routes`` / ``RunOpt_NLP`` -- the batched structured interior-point solver over the operators of
+  include/eepacc_nlp.h (assembly, Riccati sweep, rollout, rows) and the cold-start multi-start; host logic only
+  (per-route scalars and accept / reject masks), DESIGN.md section 3.8.
 * ``postprocess`` -- RunOpt_NLP.m:545-605 (derived quantities and the cost series of optSol).
-
-The interior-point iteration itself is not in the library yet.
 """
 from __future__ import annotations
 

@@ -9,13 +9,16 @@
  * evaluation for B routes at once: the objective, every constraint row, the objective gradient and the
  * Jacobian blocks of the RK4 x 4 integrator (the only rows whose derivatives are not closed-form).
  *
- * SURVEY.md section 8f rank 2 asks for the whole of RunOpt_NLP as a batched solver on the GPU.  This
- * header is the evaluation half of it; the interior-point iteration on top (stage-wise Riccati
- * factorisation, oracle/nlp_oracle.py: solve) runs on the CPU as a model only and is not part of the
- * library yet.
+ * SURVEY.md section 8f rank 2 asks for the whole of RunOpt_NLP as a batched solver on the GPU.  This header declares the
+ * operators of a structured interior-point iteration: the function evaluation (eepacc_nlp_eval, in the reference's own
+ * variable layout), the Newton-system assembly in stage form (eepacc_nlp_newton), its stage-wise factorisation
+ * (eepacc_nlp_riccati), the closed-loop nonlinear forward pass (eepacc_nlp_rollout) and the rows along a step
+ * (eepacc_nlp_rowdir).  The per-route scalar logic on top (barrier parameter, Levenberg term, step lengths, accept /
+ * reject) is host code: eepacc_mpc_casadi_matlab_amd/nlp.py (NlpSolver, RunOpt_NLP); DESIGN.md section 3.8.
  *
  * Layout: batch-major structure-of-arrays like eepacc.h -- item (k, c) of route i is x[(k*C + c)*B + i].
- * All pointers named *_dev are device allocations on the current device; tables in eepacc_nlp_problem are
+ * (eepacc_nlp_eval); the stage-form operators are route-major (a wavefront or a thread streams its own route), as their
+ * comments say.  All pointers named *_dev are device allocations on the current device; tables in eepacc_nlp_problem are
  * host pointers that eepacc_nlp_create copies.
  */
 #ifndef EEPACC_NLP_H
