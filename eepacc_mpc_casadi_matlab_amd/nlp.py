@@ -472,7 +472,7 @@ class NlpSolver(NlpEvaluator):
 
     def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
               reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False,
-              until_first=False, groups=None):
+              until_first=False, groups=None, restarts=0):
         """s_tv [B][N], chi [B][N+1][4], u [B][N][6] (a start whose states are the rollout of its controls).
         Returns dict(chi, u, J [B], status [B] (0 KKT point to `tol`, 1 iteration limit, 2 Levenberg limit), iters [B],
         kkt [B][3], lam, t)."""
@@ -497,6 +497,7 @@ class NlpSolver(NlpEvaluator):
         kkt = torch.zeros((B, 3), dtype=f64, device=dev)
         inf = torch.full((B,), float("inf"), dtype=f64, device=dev)
         b3 = lambda x: x[:, None, None]
+        n_restart = torch.zeros(B, dtype=torch.int32, device=dev)
         if until_first and groups is None:
             groups = torch.zeros(B, dtype=torch.int64, device=dev)
         if groups is not None:                              # starts of one problem share a group: the first KKT point ends it
@@ -594,6 +595,19 @@ class NlpSolver(NlpEvaluator):
                     reg = torch.where(cont, torch.zeros_like(reg), reg)
                     skip = skip | cont
                     stop = lost & ~cont
+                    if restarts > 0:
+                        # crude restoration: re-centre the route at its current point (barrier and multipliers reset,
+                        # slacks re-opened) a few times before giving it up
+                        again = stop & (n_restart < restarts)
+                        n_restart = n_restart + again.to(torch.int32)
+                        mu = torch.where(again, torch.full_like(mu, float(mu_init)), mu)
+                        t = torch.where(b3(again), torch.clamp(-r, min=1e-2), t)
+                        lam = torch.where(b3(again), b3(mu) / t, lam)
+                        new_t, new_lam = torch.where(b3(again), t, new_t), torch.where(b3(again), lam, new_lam)
+                        rho = torch.where(again, torch.ones_like(rho), rho)
+                        skip = skip | again
+                        accepted = accepted | again
+                        stop = stop & ~again
                     status = torch.where(stop, torch.full_like(status, 2), status)
                     active = active & ~stop
                     accepted = accepted | cont
