@@ -161,3 +161,31 @@ def test_saved_solution_is_a_kkt_point_of_the_restated_nlp():
     assert abs(R["J"] / J_saved - 1) < 1e-6
     assert np.abs(R["chi"][:, 1] - G["v_opt"]).max() < 0.05
     assert np.abs(R["chi"][:, 0] - G["s_opt"]).max() < 0.5
+
+
+def test_host_start_generator_matches_the_oracle_start():
+    """Product host code without a GPU: nlp.car_following_start (vectorised over lead traces, optional look-ahead) gives the
+    oracle's car-following start for look-ahead 0, stays behind the lead vehicle, and is independent per trace."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import car_following_start, build_tables
+    OPT, V, s_tv, _ = make_case(tree="ABO")
+    OPT["t_sim"] = 120.0
+    P = M.NlpProblem(OPT, V, s_tv)
+    T = build_tables(OPT)
+    f0 = car_following_start(OPT, V, T, P.s_tv)
+    c, u = M.initial_point(P)
+    assert np.abs(f0 - u[:, :2]).max() < 1e-9
+    stv = np.stack([P.s_tv, P.s_tv + 7.0, P.s_tv * 1.05])
+    fb = car_following_start(OPT, V, T, stv, lookahead=np.array([0, 60, 120]), tau=np.array([2.0, 8.0, 4.0]))
+    assert fb.shape == (3, P.N, 2) and np.abs(fb[0] - f0).max() == 0.0
+    for i in range(3):
+        one = car_following_start(OPT, V, T, stv[i], lookahead=[0, 60, 120][i], tau=[2.0, 8.0, 4.0][i])
+        assert np.array_equal(one, fb[i])
+        P.s_tv = stv[i].copy()
+        chi = np.zeros((P.N + 1, 4))
+        chi[0, 2] = -P.drag(0.0, 0.0) / (V["lambda"] * V["m"])
+        w = np.zeros((P.N, 6))
+        w[:, :2] = fb[i]
+        chi, _ = M.rollout(P, chi, w, chi, None, None, 0.0)
+        # the start keeps v >= 0 and stays behind the lead vehicle; the hard row s <= s_tv - h_min may be missed by the
+        # braking overshoot of the heuristic (measured: 0.6 m), which the solver treats as a row that does not hold yet
+        assert chi[:, 1].min() > -1e-9 and (chi[1:, 0] - (stv[i] - P.h_min)).max() < 1.0
