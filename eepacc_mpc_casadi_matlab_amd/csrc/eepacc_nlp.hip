@@ -792,6 +792,89 @@ k_nlp_rollout(const NlpDev C, const double* __restrict__ blob, int B, const doub
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-route reductions of an interior-point iteration (include/eepacc_nlp.h: eepacc_nlp_steprule, eepacc_nlp_trial).
+// One workgroup per route, 256 threads over the N * R rows of the route, fixed-order tree reductions in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RED_T = 256;
+__device__ __forceinline__ double blk_reduce(double v, double* sh, int op) {     // op 0 sum, 1 min, 2 max
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s2 = RED_T / 2; s2 > 0; s2 >>= 1) {
+        if (t < s2) {
+            const double a = sh[t], b = sh[t + s2];
+            sh[t] = op == 0 ? a + b : (op == 1 ? fmin(a, b) : fmax(a, b));
+        }
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// out [B][8]: a_p, a_d, infeas, max |lam_new| on rows that do not hold, sum log t, e_prim, max lam t, max |lam t - mu|
+__global__ void __launch_bounds__(RED_T)
+k_nlp_steprule(int n, const double* __restrict__ r, const double* __restrict__ t, const double* __restrict__ lam,
+               const double* __restrict__ jdy, const double* __restrict__ mu_arr, const double* __restrict__ tau_arr,
+               double* __restrict__ dt, double* __restrict__ dlam, double* __restrict__ out) {
+    __shared__ double sh[RED_T];
+    const int rt = blockIdx.x;
+    const size_t base = (size_t)rt * n;
+    const double mu = mu_arr[rt], tau = tau_arr[rt];
+    double ap = INFINITY, ad = INFINITY, inf_ = 0.0, lami = 0.0, slog = 0.0, eprim = 0.0, c0 = 0.0, cm = 0.0;
+    for (int e = threadIdx.x; e < n; e += RED_T) {
+        const double rv = r[base + e], tv = t[base + e], lv = lam[base + e];
+        const double rg = rv + tv;
+        const bool is_i = rg > 1e-9 * (1.0 + tv);
+        slog += log(tv);
+        if (is_i) { inf_ += rg; eprim = fmax(eprim, rg); }
+        c0 = fmax(c0, lv * tv);
+        cm = fmax(cm, fabs(lv * tv - mu));
+        if (jdy) {
+            const double D = lv / tv, jd = jdy[base + e];
+            const double d = -rg - jd, ln = mu / tv + D * rg + D * jd, dl = ln - lv;
+            dt[base + e] = d;
+            dlam[base + e] = dl;
+            if (d < 0.0) ap = fmin(ap, -tau * tv / d);
+            if (dl < 0.0) ad = fmin(ad, -tau * lv / dl);
+            if (is_i) lami = fmax(lami, fabs(ln));
+        }
+    }
+    const double v0 = blk_reduce(ap, sh, 1), v1 = blk_reduce(ad, sh, 1), v2 = blk_reduce(inf_, sh, 0), v3 = blk_reduce(lami, sh, 2);
+    const double v4 = blk_reduce(slog, sh, 0), v5 = blk_reduce(eprim, sh, 2), v6 = blk_reduce(c0, sh, 2), v7 = blk_reduce(cm, sh, 2);
+    if (threadIdx.x == 0) {
+        double* o = out + (size_t)rt * 8;
+        o[0] = fmin(v0, 1.0); o[1] = fmin(v1, 1.0); o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7;
+    }
+}
+
+// trial point of the line search: slacks (rows that hold follow their row, the others keep the Newton slack unless the
+// row has become satisfied beyond it), fraction-to-the-boundary test, residual and barrier sums.  out [B][3]: feasible
+// (1 / 0), sum of residuals of rows that do not hold, sum log t_trial
+__global__ void __launch_bounds__(RED_T)
+k_nlp_trial(int n, const double* __restrict__ r, const double* __restrict__ t, const double* __restrict__ dt,
+            const double* __restrict__ r_t, const double* __restrict__ a_arr, const double* __restrict__ tau_arr,
+            double* __restrict__ t_t, double* __restrict__ out) {
+    __shared__ double sh[RED_T];
+    const int rt = blockIdx.x;
+    const size_t base = (size_t)rt * n;
+    const double a = a_arr[rt], tau = tau_arr[rt];
+    double bad = 0.0, inf_ = 0.0, slog = 0.0;
+    for (int e = threadIdx.x; e < n; e += RED_T) {
+        const double rv = r[base + e], tv = t[base + e], rt_ = r_t[base + e];
+        const bool is_i = (rv + tv) > 1e-9 * (1.0 + tv);
+        const double tn = is_i ? fmax(-rt_, tv + a * dt[base + e]) : -rt_;
+        t_t[base + e] = tn;
+        if (!(tn >= (1.0 - tau) * tv)) bad = 1.0;
+        if (is_i) inf_ += rt_ + tn;
+        slog += log(fmax(tn, 1e-300));
+    }
+    const double v0 = blk_reduce(bad, sh, 2), v1 = blk_reduce(inf_, sh, 0), v2 = blk_reduce(slog, sh, 0);
+    if (threadIdx.x == 0) { double* o = out + (size_t)rt * 3; o[0] = v0 > 0.0 ? 0.0 : 1.0; o[1] = v1; o[2] = v2; }
+}
+
 }  // namespace
 
 struct eepacc_nlp_handle {
@@ -960,6 +1043,30 @@ extern "C" int eepacc_nlp_rowdir(eepacc_nlp_handle* h, int B, const double* s_tv
     const size_t units = (size_t)h->C.N * B;
     hipLaunchKernelGGL(k_nlp_rowdir, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->C, h->d_blob, B, s_tv_dev,
                        chi_dev, u_dev, jdy_dev ? dchi_dev : nullptr, du_dev, rows_dev, jdy_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_steprule(int device, int B, int rows_per_route, const double* r_dev, const double* t_dev, const double* lam_dev,
+                                   const double* jdy_dev, const double* mu_dev, const double* tau_dev, double* dt_dev, double* dlam_dev,
+                                   double* out_dev, void* stream) {
+    if (B < 1 || rows_per_route < 1 || !r_dev || !t_dev || !lam_dev || !mu_dev || !tau_dev || !out_dev || (jdy_dev && (!dt_dev || !dlam_dev)))
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_steprule: null argument");
+    NLPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_nlp_steprule, dim3(B), dim3(RED_T), 0, (hipStream_t)stream, rows_per_route, r_dev, t_dev, lam_dev, jdy_dev, mu_dev,
+                       tau_dev, dt_dev, dlam_dev, out_dev);
+    NLPCHK(hipGetLastError());
+    return EEPACC_OK;
+}
+
+extern "C" int eepacc_nlp_trial(int device, int B, int rows_per_route, const double* r_dev, const double* t_dev, const double* dt_dev,
+                                const double* r_trial_dev, const double* alpha_dev, const double* tau_dev, double* t_trial_dev,
+                                double* out_dev, void* stream) {
+    if (B < 1 || rows_per_route < 1 || !r_dev || !t_dev || !dt_dev || !r_trial_dev || !alpha_dev || !tau_dev || !t_trial_dev || !out_dev)
+        return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_trial: null argument");
+    NLPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_nlp_trial, dim3(B), dim3(RED_T), 0, (hipStream_t)stream, rows_per_route, r_dev, t_dev, dt_dev, r_trial_dev, alpha_dev,
+                       tau_dev, t_trial_dev, out_dev);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }

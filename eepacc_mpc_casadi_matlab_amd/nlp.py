@@ -198,6 +198,8 @@ def _bind(lib):
     lib.eepacc_nlp_newton.argtypes = [vp, C.c_int, vp, C.c_double] + [vp] * 13
     lib.eepacc_nlp_rowdir.argtypes = [vp, C.c_int] + [vp] * 8
     lib.eepacc_nlp_rollout.argtypes = [vp, C.c_int] + [vp] * 7
+    lib.eepacc_nlp_steprule.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 10
+    lib.eepacc_nlp_trial.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 9
     lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
 
@@ -440,6 +442,35 @@ class NlpSolver(NlpEvaluator):
             raise self._err("eepacc_nlp_rollout failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
         return chi_n, u_n
 
+    def _steprule(self, r, t, lam, jdy, mu, tau):
+        """eepacc_nlp_steprule: (dt, dlam, out [B][8]); dt / dlam are None without jdy."""
+        import torch
+        B = r.shape[0]
+        out = torch.empty((B, 8), dtype=torch.float64, device=r.device)
+        dt = torch.empty_like(r) if jdy is not None else None
+        dlam = torch.empty_like(r) if jdy is not None else None
+        stream = torch.cuda.current_stream(r.device).cuda_stream
+        rc = self.lib.eepacc_nlp_steprule(self.device, B, self.N * self.R, r.data_ptr(), t.data_ptr(), lam.data_ptr(),
+                                          jdy.data_ptr() if jdy is not None else None, mu.data_ptr(), tau.data_ptr(),
+                                          dt.data_ptr() if dt is not None else None, dlam.data_ptr() if dlam is not None else None,
+                                          out.data_ptr(), stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_steprule failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return dt, dlam, out
+
+    def _trial(self, r, t, dt, r_t, a, tau):
+        """eepacc_nlp_trial: (t_trial, out [B][3] = feasible, residual sum, sum log t_trial)."""
+        import torch
+        B = r.shape[0]
+        out = torch.empty((B, 3), dtype=torch.float64, device=r.device)
+        t_t = torch.empty_like(r)
+        stream = torch.cuda.current_stream(r.device).cuda_stream
+        rc = self.lib.eepacc_nlp_trial(self.device, B, self.N * self.R, r.data_ptr(), t.data_ptr(), dt.data_ptr(), r_t.data_ptr(),
+                                       a.data_ptr(), tau.data_ptr(), t_t.data_ptr(), out.data_ptr(), stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_trial failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return t_t, out
+
     def _values(self, s_tv, s_tv_bm, chi, u, sigma):
         """Scaled objective [B] and rows [B][N][R] at a point whose states are the rollout of its controls."""
         import torch
@@ -472,7 +503,7 @@ class NlpSolver(NlpEvaluator):
 
     def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
               reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False,
-              until_first=False, groups=None, restarts=0):
+              until_first=False, groups=None, restarts=0, fused=True, accept_tol=1e-13):
         """s_tv [B][N], chi [B][N+1][4], u [B][N][6] (a start whose states are the rollout of its controls).
         Returns dict(chi, u, J [B], status [B] (0 KKT point to `tol`, 1 iteration limit, 2 Levenberg limit), iters [B],
         kkt [B][3], lam, t)."""
@@ -510,11 +541,17 @@ class NlpSolver(NlpEvaluator):
                 rg = r + t
                 dchi, du, nu_new, st, work, gnorm = riccati_batched(Q, q, AB, c, reg_last, self.REG_SCALE, self.device, full=True, qlam=self.last_qlam)
                 e_dual = torch.where(st == 0, gnorm, inf)
-                rows_i = rg > 1e-9 * (1.0 + t)
-                e_prim = (rg * rows_i).amax(dim=(1, 2))
-                lt = lam * t
-                e_comp0 = lt.amax(dim=(1, 2))
-                e_compm = (lt - b3(mu)).abs().amax(dim=(1, 2))
+                tau = torch.clamp(1.0 - mu, min=tau_min)
+                if fused:
+                    _, _, m8 = self._steprule(r, t, lam, None, mu, tau)
+                    e_prim, e_comp0, e_compm = m8[:, 5], m8[:, 6], m8[:, 7]
+                    rows_i = None
+                else:
+                    rows_i = rg > 1e-9 * (1.0 + t)
+                    e_prim = (rg * rows_i).amax(dim=(1, 2))
+                    lt = lam * t
+                    e_comp0 = lt.amax(dim=(1, 2))
+                    e_compm = (lt - b3(mu)).abs().amax(dim=(1, 2))
                 err0 = torch.maximum(torch.maximum(e_dual, e_prim), e_comp0)
                 done = active & (err0 <= tol)
                 kkt = torch.where(active[:, None], torch.stack([e_dual, e_prim, e_comp0], dim=1), kkt)
@@ -550,18 +587,24 @@ class NlpSolver(NlpEvaluator):
                 first = False
                 ok = st == 0
                 _, jdy = self._rowdir(s_tv, chi, u, dchi, du)
-                Dg = lam / t
-                dt = -rg - jdy
-                lam_new = b3(mu) / t + Dg * rg + Dg * jdy
-                dlam = lam_new - lam
                 tau = torch.clamp(1.0 - mu, min=tau_min)
-                big = torch.full_like(t, float("inf"))
-                a_p = torch.clamp(torch.where(dt < 0, -b3(tau) * t / torch.where(dt < 0, dt, -torch.ones_like(dt)), big).amin(dim=(1, 2)), max=1.0)
-                a_d = torch.clamp(torch.where(dlam < 0, -b3(tau) * lam / torch.where(dlam < 0, dlam, -torch.ones_like(dlam)), big).amin(dim=(1, 2)), max=1.0)
-                infeas = (rg * rows_i).sum(dim=(1, 2))
-                lam_i = torch.nan_to_num((lam_new.abs() * rows_i).amax(dim=(1, 2)), nan=0.0, posinf=0.0)
+                if fused:
+                    dt, dlam, m8 = self._steprule(r, t, lam, jdy, mu, tau)
+                    a_p, a_d, infeas, lam_i, sumlog = m8[:, 0].contiguous(), m8[:, 1].contiguous(), m8[:, 2], m8[:, 3], m8[:, 4]
+                else:
+                    Dg = lam / t
+                    dt = -rg - jdy
+                    lam_new = b3(mu) / t + Dg * rg + Dg * jdy
+                    dlam = lam_new - lam
+                    big = torch.full_like(t, float("inf"))
+                    a_p = torch.clamp(torch.where(dt < 0, -b3(tau) * t / torch.where(dt < 0, dt, -torch.ones_like(dt)), big).amin(dim=(1, 2)), max=1.0)
+                    a_d = torch.clamp(torch.where(dlam < 0, -b3(tau) * lam / torch.where(dlam < 0, dlam, -torch.ones_like(dlam)), big).amin(dim=(1, 2)), max=1.0)
+                    infeas = (rg * rows_i).sum(dim=(1, 2))
+                    lam_i = (lam_new.abs() * rows_i).amax(dim=(1, 2))
+                    sumlog = torch.log(t).sum(dim=(1, 2))
+                lam_i = torch.nan_to_num(lam_i, nan=0.0, posinf=0.0)
                 rho = torch.where((infeas > 0) & ok & need, torch.maximum(rho, 1.1 * lam_i), rho)   # only from a valid factorisation
-                phi0 = cost - mu * torch.log(t).sum(dim=(1, 2)) + rho * infeas
+                phi0 = cost - mu * sumlog + rho * infeas
                 a = a_p.clone()
                 acc_now = torch.zeros(B, dtype=torch.bool, device=dev)
                 for ls in range(max_ls):
@@ -570,11 +613,16 @@ class NlpSolver(NlpEvaluator):
                         break
                     chi_t, u_t = self.rollout(chi, u, work, a)
                     cost_t, r_t = self._values(s_tv, s_tv_bm, chi_t, u_t, sigma)
-                    t_t = torch.where(rows_i, torch.maximum(-r_t, t + b3(a) * dt), -r_t)
-                    feas = (t_t >= (1.0 - b3(tau)) * t).all(dim=2).all(dim=1)
-                    inf_t = ((r_t + t_t) * rows_i).sum(dim=(1, 2))
-                    phi_t = cost_t - mu * torch.log(torch.clamp(t_t, min=1e-300)).sum(dim=(1, 2)) + rho * inf_t
-                    good = trial & feas & (phi_t <= phi0 + 1e-13 * phi0.abs())
+                    if fused:
+                        t_t, m3 = self._trial(r, t, dt, r_t, a.contiguous(), tau)
+                        feas, inf_t, sumlog_t = m3[:, 0] > 0.5, m3[:, 1], m3[:, 2]
+                    else:
+                        t_t = torch.where(rows_i, torch.maximum(-r_t, t + b3(a) * dt), -r_t)
+                        feas = (t_t >= (1.0 - b3(tau)) * t).all(dim=2).all(dim=1)
+                        inf_t = ((r_t + t_t) * rows_i).sum(dim=(1, 2))
+                        sumlog_t = torch.log(torch.clamp(t_t, min=1e-300)).sum(dim=(1, 2))
+                    phi_t = cost_t - mu * sumlog_t + rho * inf_t
+                    good = trial & feas & (phi_t <= phi0 + accept_tol * phi0.abs())
                     g3 = b3(good)                                   # masked selects, no host round trip
                     new_chi, new_u, new_t = torch.where(g3, chi_t, new_chi), torch.where(g3, u_t, new_u), torch.where(g3, t_t, new_t)
                     new_cost = torch.where(good, cost_t, new_cost)
@@ -677,7 +725,8 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
     return out[0] if single else out
 
 
-def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500):
+def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500,
+                 fused: bool = False):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
     gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch.  Returns
     per route: J, status, iterations, index of the winning start, chi [R][N+1][4], u [R][N][6]."""
@@ -693,7 +742,9 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
                                  tau=np.tile([float(tc) for (_, tc) in starts], Rn))
     groups = np.repeat(np.arange(Rn), S)
     chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1)), forces, margin=1.0)
-    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups)
+    # fused = False: on the reference's ABO scenario the one start that reaches the KKT tolerance does so only with the
+    # tensor-operation reductions (the fused kernels sum in another order and that start then ends 8e-6 above)
+    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused)
     st = R["status"].view(Rn, S)
     J = torch.where(st == 0, R["J"].view(Rn, S), R["J"].view(Rn, S) + 1e30)       # a KKT point beats any unfinished start
     win = J.argmin(dim=1)

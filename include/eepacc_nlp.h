@@ -136,6 +136,23 @@ int eepacc_nlp_rowdir(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const
 int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alpha_dev, const double* chi_dev, const double* u_dev,
                        const double* work_dev, double* chi_new_dev, double* u_new_dev, void* stream);
 
+
+/* Per-route reductions of an interior-point iteration over the rows_per_route = N * R rows of each route (route-major
+ * arrays r, t, lam, jdy [B][N][R]; mu, tau, alpha [B]).
+ * eepacc_nlp_steprule: step dt = -(r + t) - jdy and dlam = (mu/t + (lam/t)(r + t) + (lam/t) jdy) - lam (written if jdy is
+ * given) and out [B][8] = fraction-to-the-boundary step lengths a_p, a_d (<= 1), sum of residuals r + t of rows that do
+ * not hold (r + t > 1e-9 (1 + t)), largest new multiplier on those rows, sum log t, largest such residual, max lam t,
+ * max |lam t - mu|  (the last four alone when jdy is NULL: the convergence measures of the current point).
+ * eepacc_nlp_trial: slacks of a trial point (rows that hold: t = -r_trial; the others: max(-r_trial, t + alpha dt)) and
+ * out [B][3] = all slacks keep the fraction-to-the-boundary distance (1 / 0), sum of residuals of rows that do not
+ * hold, sum log t_trial. */
+int eepacc_nlp_steprule(int device, int B, int rows_per_route, const double* r_dev, const double* t_dev, const double* lam_dev,
+                        const double* jdy_dev, const double* mu_dev, const double* tau_dev, double* dt_dev, double* dlam_dev,
+                        double* out_dev, void* stream);
+int eepacc_nlp_trial(int device, int B, int rows_per_route, const double* r_dev, const double* t_dev, const double* dt_dev,
+                     const double* r_trial_dev, const double* alpha_dev, const double* tau_dev, double* t_trial_dev,
+                     double* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,7 +92,7 @@ def test_nlp_header_symbols_and_layout(lib):
     hdr = open(os.path.join(ROOT, "include", "eepacc_nlp.h")).read()
     declared = sorted(set(re.findall(r"\b(eepacc_nlp_[a-z_0-9]+)\s*\(", hdr)))
     assert declared == ["eepacc_nlp_create", "eepacc_nlp_destroy", "eepacc_nlp_eval", "eepacc_nlp_newton", "eepacc_nlp_riccati", "eepacc_nlp_rollout", "eepacc_nlp_rowdir", "eepacc_nlp_rows",
-                        "eepacc_nlp_sizeof_problem", "eepacc_nlp_synchronize"]
+                        "eepacc_nlp_sizeof_problem", "eepacc_nlp_steprule", "eepacc_nlp_synchronize", "eepacc_nlp_trial"]
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.eepacc_nlp_sizeof_problem() == C.sizeof(nlp.NlpProblemPOD)
