@@ -726,7 +726,7 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
 
 
 def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500,
-                 fused: bool = False):
+                 fused: bool = False, restarts: int = 3):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
     gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch.  Returns
     per route: J, status, iterations, index of the winning start, chi [R][N+1][4], u [R][N][6]."""
@@ -744,7 +744,8 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
     chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1)), forces, margin=1.0)
     # fused = False: on the reference's ABO scenario the one start that reaches the KKT tolerance does so only with the
     # tensor-operation reductions (the fused kernels sum in another order and that start then ends 8e-6 above)
-    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused)
+    # restarts = 3: with the re-centring restoration a start reaches the saved ABO solution in either arithmetic
+    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused, restarts=restarts)
     st = R["status"].view(Rn, S)
     J = torch.where(st == 0, R["J"].view(Rn, S), R["J"].view(Rn, S) + 1e30)       # a KKT point beats any unfinished start
     win = J.argmin(dim=1)
