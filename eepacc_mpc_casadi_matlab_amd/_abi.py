@@ -18,11 +18,14 @@ OUT = {name: i for i, name in enumerate(OUT_FIELDS)}
 _VEH_FIELDS = ["m", "A_f", "c_d", "L", "h_g", "WD_s_F", "L_f", "L_r", "F0", "F1", "F2",
                "p00", "p10", "p01", "P_m_max", "T_m_max", "omega_m_r", "omega_m_max",
                "c_r", "R_w", "beta_gb", "beta_fd", "phi", "v_max", "eta_TF",
-               "lambda", "mu", "rho_a", "g", "zeta_a"]
+               "lambda", "mu", "rho_a", "g", "zeta_a",
+               "k00", "k10", "k01", "tau_fd", "eta_drive"]
+_VEH_OPTIONAL = {"k00": 0.0, "k10": 0.0, "k01": 0.0, "tau_fd": 1.0, "eta_drive": 1.0}
 
 
 class Vehicle(C.Structure):
-    _fields_ = [(("lambda_" if f == "lambda" else f), C.c_double) for f in _VEH_FIELDS]
+    _fields_ = ([(("lambda_" if f == "lambda" else f), C.c_double) for f in _VEH_FIELDS]
+                + [("upSpd", C.c_double * 7), ("tau_gb", C.c_double * 8)])
 
 
 class SettingsPOD(C.Structure):
@@ -61,7 +64,15 @@ class SettingsPOD(C.Structure):
 def make_vehicle(V: Dict[str, float]) -> Vehicle:
     v = Vehicle()
     for f in _VEH_FIELDS:
-        setattr(v, "lambda_" if f == "lambda" else f, float(V[f]))
+        setattr(v, "lambda_" if f == "lambda" else f, float(V[f] if f not in _VEH_OPTIONAL else V.get(f, _VEH_OPTIONAL[f])))
+    up = np.asarray(V.get("upSpd", np.full(7, 1e9)), dtype=np.float64).ravel()
+    gb = np.asarray(V.get("tau_gb", np.ones(8)), dtype=np.float64).ravel()
+    if up.size != 7 or gb.size != 8:
+        raise ValueError("upSpd needs 7 and tau_gb 8 entries (SetVehicleParameters.m:96-98)")
+    for i in range(7):
+        v.upSpd[i] = float(up[i])
+    for i in range(8):
+        v.tau_gb[i] = float(gb[i])
     return v
 
 
@@ -82,7 +93,7 @@ class SettingsHolder:
         p.Mb = mb.ctypes.data_as(c_int32_p)
         W_AB = np.asarray(OPT["W_AB"], dtype=np.float64).ravel()
         if W_AB.size == 7:
-            p.ab_fuel_term = 1
+            p.ab_fuel_term = 2 if OPT.get("fuel_map", "EFF") == "ICE" else 1     # CreateQP_AB.m:154-166
             wab = W_AB
         elif W_AB.size == 6:       # ORIG/Settings.m:48-62: no w_FC entry
             p.ab_fuel_term = 0

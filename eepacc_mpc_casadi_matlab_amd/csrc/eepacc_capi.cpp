@@ -116,6 +116,9 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         S->n_TL < 0 || S->n_TL > eepacc::kMaxTL)
         return fail(EEPACC_EINVAL, "route table sizes out of range");
     if (S->N_integratePlant < 1) return fail(EEPACC_EINVAL, "N_integratePlant < 1");
+    if (S->ab_fuel_term < 0 || S->ab_fuel_term > 2) return fail(EEPACC_EINVAL, "ab_fuel_term must be 0, 1 or 2");
+    if (S->ab_fuel_term == 2 && !S->bl_mode)
+        return fail(EEPACC_ENOTSUP, "ab_fuel_term == 2 (ICE-map fuel term, CreateQP_AB.m:154-159: step-varying Hessian) is not built");
     C.N = N;
     C.ab_fuel_term = S->ab_fuel_term; C.ab_route_rows = S->ab_route_rows;
     C.paramEstSetting = S->paramEstSetting; C.TVestSetting = S->TVestSetting;

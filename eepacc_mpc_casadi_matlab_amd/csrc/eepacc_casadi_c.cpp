@@ -111,6 +111,16 @@ bool parse(const char* path, Config& c) {
     VEH(m); VEH(A_f); VEH(c_d); VEH(L); VEH(h_g); VEH(WD_s_F); VEH(L_f); VEH(L_r); VEH(F0); VEH(F1); VEH(F2);
     VEH(p00); VEH(p10); VEH(p01); VEH(P_m_max); VEH(T_m_max); VEH(omega_m_r); VEH(omega_m_max); VEH(c_r); VEH(R_w);
     VEH(beta_gb); VEH(beta_fd); VEH(phi); VEH(v_max); VEH(eta_TF); VEH(lambda); VEH(mu); VEH(rho_a); VEH(g); VEH(zeta_a);
+    V.tau_fd = 1.0; V.eta_drive = 1.0;
+    for (int i = 0; i < 7; ++i) V.upSpd[i] = 1e9;
+    for (int i = 0; i < 8; ++i) V.tau_gb[i] = 1.0;
+    VEH(k00); VEH(k10); VEH(k01); VEH(tau_fd); VEH(eta_drive);
+    { const auto* up = get(c, "vehicle.upSpd"); const auto* gb = get(c, "vehicle.tau_gb");
+      if (up && gb) {
+          if (up->size() != 7 || gb->size() != 8) return false;
+          for (int i = 0; i < 7; ++i) V.upSpd[i] = (*up)[i];
+          for (int i = 0; i < 8; ++i) V.tau_gb[i] = (*gb)[i];
+      } }
 #undef VEH
 #undef REQ
 #undef REQI

@@ -32,6 +32,10 @@ def SetVehicleParameters(tree: str = "ABO") -> Dict[str, float]:
         V.update(F0=275.0, F1=0.0, F2=1.305072)                       # :32-34
         V.update(p00=-1.178, p10=0.1154, p01=0.001764)                # :80-82
         V.update(c_r=0.0107, R_w=0.361)                               # :91-92
+        # ICE fuel map and stepped gearbox (:44-46, :96-101), read by the ICE-map fuel term (OPT["fuel_map"] = "ICE")
+        V.update(k00=-2.134, k10=0.01164, k01=0.01041, tau_fd=3.615, eta_drive=0.94 * 0.94)
+        V["upSpd"] = np.array([15, 25, 30, 40, 55, 70, 85], dtype=np.float64) / (3.6 * 1.05)
+        V["tau_gb"] = np.array([4.714, 3.314, 2.106, 1.667, 1.285, 1, 0.839, 0.667])
     elif tree == "ORIG":   # ORIG/.../SetVehicleParameters.m (BMW i3)
         V.update(m=1443.0, A_f=2.38, c_d=0.29, L=2.57, h_g=0.47, WD_s_F=0.53)
         V.update(F0=0.0, F1=0.0, F2=0.0, p00=0.0, p10=0.0, p01=0.0)

@@ -57,6 +57,13 @@ typedef struct eepacc_vehicle {
     double v_max;
     double eta_TF;
     double lambda, mu, rho_a, g, zeta_a;
+    /* ICE fuel-map fit FC = k00 + k10*w_ICE + k01*T_ICE and the stepped gearbox it needs
+     * (ABO/Functions/Settings/SetVehicleParameters.m:44-46,96-101; gear choice per horizon stage:
+     * ABO/Functions/MPCs/LUTgearshift.m:17-41).  Read only when ab_fuel_term = 2. */
+    double k00, k10, k01;
+    double tau_fd, eta_drive;
+    double upSpd[7];               /* upshift speed thresholds, m/s, ascending          */
+    double tau_gb[8];              /* gearbox ratio of gears 1..8                       */
 } eepacc_vehicle;
 
 /* Controller / scenario settings: the fields of OPTsettings read on the hot path
@@ -71,7 +78,11 @@ typedef struct eepacc_settings {
      * [0,w_a,w_j,w_v,w_h,w_s,w_f].  W_FB: ABO/Settings.m:31-46 [w_P,w_a,w_j,w_v,w_h,w_s,w_f] */
     double  W_AB[7];
     double  W_FB[7];
-    int32_t ab_fuel_term;          /* 1: ABO/.../CreateQP_AB.m:162-166 present           */
+    int32_t ab_fuel_term;          /* 1: efficiency-map fuel term ABO/.../CreateQP_AB.m:162-166;
+                                    * 2: the ICE-map fuel term of :154-159 (what savedABMPCsolICEMAP.mat was
+                                    *    written with): per-stage curvature 2 w_FC k01 F2 R_w/(tau_fd tau_est(k) eta_drive)
+                                    *    with the gear ratio tau_est(k) = LUTgearshift(v_est(k)), so H changes every
+                                    *    step; 0: no fuel term (ORIG)                                               */
     int32_t ab_route_rows;         /* 1: ORIG 18-row stage (speed/curve/stop/TL caps)    */
     /* vehicle following (ABO/Settings.m:203-204,143) */
     double  tau_min, h_min, s_goal;

@@ -83,7 +83,16 @@ static void emx_vehicle(eepacc_vehicle* V) {
     EMX_V(P_m_max, 1); EMX_V(T_m_max, 1); EMX_V(omega_m_r, 1); EMX_V(omega_m_max, 0);
     EMX_V(c_r, 1); EMX_V(R_w, 0); EMX_V(beta_gb, 0); EMX_V(beta_fd, 0); EMX_V(phi, 1);
     EMX_V(v_max, 1); EMX_V(eta_TF, 1); EMX_V(mu, 1); EMX_V(rho_a, 0); EMX_V(g, 1); EMX_V(zeta_a, 1);
+    EMX_V(k00, 0); EMX_V(k10, 0); EMX_V(k01, 0); EMX_V(tau_fd, 0); EMX_V(eta_drive, 0);         /* ICE map, :44-46,100-101 */
 #undef EMX_V
+    { const mxArray* up = mxGetField(out, 0, "upSpd"); const mxArray* gb = mxGetField(out, 0, "tau_gb");   /* :97-99 */
+      int i;
+      for (i = 0; i < 7; ++i) V->upSpd[i] = 1e9;
+      for (i = 0; i < 8; ++i) V->tau_gb[i] = 1.0;
+      if (up && gb && mxGetNumberOfElements(up) == 7 && mxGetNumberOfElements(gb) == 8) {
+          for (i = 0; i < 7; ++i) V->upSpd[i] = mxGetPr(up)[i];
+          for (i = 0; i < 8; ++i) V->tau_gb[i] = mxGetPr(gb)[i];
+      } }
     { const mxArray* f_ = mxGetField(out, 0, "lambda");
       if (!f_) mexErrMsgIdAndTxt("eepacc:vehicle", "V.lambda is missing");
       V->lambda = mxGetScalar(f_); }

@@ -156,6 +156,15 @@ void orc_estimate_route_and_comfort_bounds(const eepacc_settings* S, const doubl
     }
 }
 
+/* ABO/Functions/MPCs/LUTgearshift.m:17-41: gear ratio from the estimated speed.  The reference compares with strict
+ * inequalities on both sides, so a speed exactly on a threshold leaves its output unassigned (a MATLAB error); here
+ * such a speed takes the higher gear. */
+double orc_lut_gearshift(const eepacc_vehicle* V, double v) {
+    int g = 0;
+    while (g < 7 && !(v < V->upSpd[g])) ++g;
+    return V->tau_gb[g];
+}
+
 static int count_mb(const eepacc_settings* S) {
     int c = 0;
     if (S->Mb) for (int k = 0; k < S->N_hor; ++k) c += (S->Mb[k] == 1);
@@ -197,10 +206,19 @@ void orc_create_qp_ab(const eepacc_settings* S, const eepacc_vehicle* V, double 
         const double T = S->Tvec[kk];
         const int o = kk * n_x_u;
         const double v_minInc = v_lim[kk] < v_curv[kk] ? v_lim[kk] : v_curv[kk];   /* :55 */
+        if (S->ab_fuel_term == 2) {
+            /* objective: fuel term, ICE map :154-159 (commented in the checked-in file; savedABMPCsolICEMAP.mat was
+             * written with it), tau_est(k) = LUTgearshift(v_est(k)), EstimateRouteAndComfortBounds.m:63-66 */
+            const double tau = orc_lut_gearshift(V, v_est[kk]);
+            H[IDX(o + vcurr, o + vcurr, nz)] += w_FC * (2.0 * V->k01 * V->F2 * V->R_w / V->tau_fd / tau / V->eta_drive);
+            c[o + vcurr] += w_FC * (V->k10 / V->R_w * V->tau_fd * tau);
+            c[o + acurr] += w_FC * (V->k01 * V->lambda * V->m * V->R_w / V->tau_fd / tau / V->eta_drive);
+        } else {
         /* objective: fuel term :162-166 */
         H[IDX(o + vcurr, o + vcurr, nz)] += w_FC * 2.0 * V->p01 * V->F2;
         c[o + vcurr] += w_FC * V->p10;
         c[o + acurr] += w_FC * V->p01 * V->lambda * V->m;
+        }
         /* acceleration :169-170 */
         H[IDX(o + acurr, o + acurr, nz)] += 2.0 * w_a;
         /* jerk :173-180 */

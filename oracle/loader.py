@@ -80,6 +80,12 @@ class Oracle:
                                                       C.c_double, C.c_double, c_double_p, c_double_p,
                                                       c_double_p, c_double_p]
 
+    def lib_lut(self, v):
+        """ABO/Functions/MPCs/LUTgearshift.m:17-41"""
+        self.lib.orc_lut_gearshift.restype = C.c_double
+        self.lib.orc_lut_gearshift.argtypes = [C.POINTER(Vehicle), C.c_double]
+        return float(self.lib.orc_lut_gearshift(C.byref(self.V), float(v)))
+
     # sizes --------------------------------------------------------------------------------
     def nC(self, kind="ab"):
         if kind == "ab" and self.S.bl_mode:

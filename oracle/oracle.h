@@ -43,6 +43,9 @@ void orc_estimate_route_and_comfort_bounds(const eepacc_settings* S, const doubl
                                            double* v_curv_max, double* a_min_est, double* a_max_est,
                                            double* j_min_est, double* j_max_est);
 
+/* ABO/Functions/MPCs/LUTgearshift.m:17-41 */
+double orc_lut_gearshift(const eepacc_vehicle* V, double v);
+
 /* number of constraint rows of the trimmed sparse-form QP / variables */
 int orc_ab_num_rows(const eepacc_settings* S);
 int orc_bl_num_rows(const eepacc_settings* S);      /* ABO/Functions/MPCs/CreateQP_BL.m, dense form: 13 N + 2 */

@@ -33,6 +33,13 @@ GOLDEN_AB_VARIANTS = {
 }
 
 
+# savedABMPCsolICEMAP.mat: the EFFMAP weights (same cost_* ratios, xi_h diagonal 0.2) with the ICE-map fuel term of
+# CreateQP_AB.m:154-159 (commented in the checked-in file): k10, k01 of SetVehicleParameters.m:44-46, gear ratio per
+# horizon stage from LUTgearshift.m -- the saved H's per-stage v^2 coefficient at standstill (first gear) is
+# 2*1000*k01*F2*R_w/tau_fd/4.714/eta_drive = 0.65144.
+GOLDEN_AB_ICEMAP = dict(W_AB=[1000.0, 30.0, 1000.0, 800.0, 0.1, 9e7, 1e7], fuel_map="ICE")
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

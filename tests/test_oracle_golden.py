@@ -7,7 +7,7 @@ per-step QP outputs and the 871-step closed loop, post-processing.  CPU only.
 import numpy as np
 import pytest
 
-from conftest import load_golden, make_case, golden_step_inputs, GOLDEN_AB_VARIANTS
+from conftest import load_golden, make_case, golden_step_inputs, GOLDEN_AB_VARIANTS, GOLDEN_AB_ICEMAP
 from eepacc_mpc_casadi_matlab_amd._abi import OUT
 from oracle import Oracle
 from oracle.loader import LoopState
@@ -127,6 +127,32 @@ def test_ab_weight_variants_closed_loop_and_H(name):
     r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, 870), want_dense=True)
     assert np.abs(r["G"] - G["G"]).max() <= 1e-13
     assert np.abs(r["H"] - G["H"]).max() <= 1e-12 * np.abs(G["H"]).max()
+
+
+def test_ab_icemap_closed_loop_and_H():
+    """savedABMPCsolICEMAP.mat: ABMPC with the ICE-map fuel term (CreateQP_AB.m:154-159; gear ratio per stage from
+    LUTgearshift(v_est(k)), EstimateRouteAndComfortBounds.m:63-66), so the Hessian changes from step to step.  The
+    871-step closed loop at the tolerances of the other saved ABMPC solutions, and the final-step dense H, G."""
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    OPT = dict(OPT); OPT["W_AB"] = np.array(GOLDEN_AB_ICEMAP["W_AB"]); OPT["fuel_map"] = GOLDEN_AB_ICEMAP["fuel_map"]
+    G = load_golden("abo_abmpc_icemap")
+    orc = Oracle(OPT, V)
+    r = orc.ab_step(**golden_step_inputs(G, s_tv, v_tv, 870), want_dense=True)
+    assert np.abs(r["G"] - G["G"]).max() <= 1e-13
+    assert np.abs(r["H"] - G["H"]).max() <= 1e-12 * np.abs(G["H"]).max()
+    ref, st, _ = orc.run("ab", 871, 0.0, 0.0, 0.0, s_tv, v_tv)
+    assert st.sum() == 0 and G["exitMessage"].sum() == 0
+    # tolerances of test_closed_loop_871_steps; measured: s 1.1e-10, v 2.9e-11, xi_h 8.8e-11, Fm 2.5e-7 N
+    for n, g, tol in (("s", "s_opt", 1e-8), ("v", "v_opt", 1e-9), ("xi_v", "xi_v_opt", 1e-9), ("xi_h", "xi_h_opt", 1e-9),
+                      ("xi_s", "xi_s_opt", 1e-9), ("xi_f", "xi_f_opt", 1e-9), ("Fm", "Fm_opt", 1e-6), ("Fb", "Fb_opt", 1e-6),
+                      ("a", "a_opt", 1e-9)):
+        assert np.abs(ref[:, OUT[n]] - G[g]).max() < tol, n
+    rpm, Tm, P, E = orc.postprocess(ref[:, OUT["v"]], ref[:, OUT["Fm"]])
+    assert abs(E[-1] - G["E_opt"][-1]) < 1e-9 * abs(G["E_opt"][-1])
+    # the gear really changes along the horizon: several distinct v^2 curvatures in one step's sparse-form objective
+    k = int(np.argmax(G["v_opt"]))
+    taus = {orc.lib_lut(v) for v in np.linspace(0.0, float(G["v_opt"][k]), 50)}
+    assert len(taus) >= 3
 
 
 @pytest.mark.parametrize("tree", TREES)

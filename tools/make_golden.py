@@ -86,7 +86,9 @@ def main():
     extract(os.path.join(ABO, "savedFBMPCsol.mat"), "FBMPCsol", "abo_fbmpc.npz")
     # ABMPC runs saved with other weight sets / fuel terms (the commented alternatives of ABO/Settings.m:48-64); the
     # weights are recovered in tests/conftest.py (GOLDEN_AB_VARIANTS) from the cost_* series and the final H.
-    # savedABMPCsolICEMAP.mat is not extracted: its fuel-map constants are not in the tree ("parity unpinned")
+    # savedABMPCsolICEMAP.mat: written with the ICE-map fuel term of CreateQP_AB.m:154-159 (k10, k01 of
+    # SetVehicleParameters.m:44-46, gear ratio per stage from LUTgearshift.m) and the EFFMAP weights
+    extract(os.path.join(ABO, "savedABMPCsolICEMAP.mat"), "ABMPCsolICEMAP", "abo_abmpc_icemap.npz")
     extract(os.path.join(ABO, "savedABMPCsolEFFMAP.mat"), "ABMPCsolEFFMAP", "abo_abmpc_effmap.npz")
     extract(os.path.join(ABO, "savedABMPCsolFCopt.mat"), "ABMPCsolFCopt", "abo_abmpc_fcopt.npz")
     extract(os.path.join(ABO, "savedABMPCsolnoFCopt.mat"), "ABMPCsolnoFCopt", "abo_abmpc_nofcopt.npz")
