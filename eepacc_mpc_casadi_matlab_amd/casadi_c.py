@@ -6,7 +6,7 @@ from typing import Any, Dict
 
 import numpy as np
 
-from ._abi import _VEH_FIELDS
+from ._abi import _VEH_FIELDS, _VEH_OPTIONAL
 
 
 def write_config(path: str, OPT: Dict[str, Any], V: Dict[str, float]) -> None:
@@ -14,7 +14,7 @@ def write_config(path: str, OPT: Dict[str, Any], V: Dict[str, float]) -> None:
     def arr(x):
         return " ".join(repr(float(v)) for v in np.asarray(x, dtype=np.float64).ravel())
     W_AB = np.asarray(OPT["W_AB"], dtype=np.float64).ravel()
-    fuel = int(W_AB.size == 7)
+    fuel = (2 if OPT.get("fuel_map", "EFF") == "ICE" else 1) if W_AB.size == 7 else 0
     if W_AB.size == 6:
         W_AB = np.concatenate([[0.0], W_AB])
     lines = ["# eepacc casadi_c settings file", "N_hor %d" % int(OPT["N_hor"]), "Tvec " + arr(OPT["Tvec"]),
@@ -33,6 +33,10 @@ def write_config(path: str, OPT: Dict[str, Any], V: Dict[str, float]) -> None:
     if np.asarray(OPT.get("TLLoc", [])).size:
         lines.append("TLLoc " + arr(np.asarray(OPT["TLLoc"], dtype=np.float64).reshape(-1, 4)))
     for f in _VEH_FIELDS:
-        lines.append("vehicle.%s %r" % (f, float(V[f])))
+        if f in V or f not in _VEH_OPTIONAL:
+            lines.append("vehicle.%s %r" % (f, float(V[f])))
+    if "upSpd" in V and "tau_gb" in V:
+        lines.append("vehicle.upSpd " + arr(V["upSpd"]))
+        lines.append("vehicle.tau_gb " + arr(V["tau_gb"]))
     with open(path, "w") as fh:
         fh.write("\n".join(lines) + "\n")

@@ -583,9 +583,9 @@ extern "C" int eepacc_fb_step(eepacc_handle* h, int B, const double* s, const do
         h->fb_k_done += 1; h->last_B = B; h->fb_by_step = true;
         return EEPACC_OK;
     }
-    h->fb_by_step = true;
     int rc = fb_prepare(h, B);
     if (rc != EEPACC_OK) return rc;
+    h->fb_by_step = true;              // after fb_prepare: its first (re)allocation clears the flag
     return fb_one_step(h, B, 0, s, v, a_prev, t0, s_tv, v_tv, a_tv_prev, out, s_pred, v_pred, status, (hipStream_t)stream);
 }
 

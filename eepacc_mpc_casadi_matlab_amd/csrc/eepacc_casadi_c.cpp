@@ -99,11 +99,17 @@ bool parse(const char* path, Config& c) {
     if (!bq || bq->size() != 6 || !b5 || b5->size() != 21) return false;
     for (int i = 0; i < 6; ++i) S.b_quadr[i] = (*bq)[i];
     for (int i = 0; i < 21; ++i) S.b_fifthOrder[i] = (*b5)[i];
+    // paired tables must have equal lengths (the MEX reader checks the same, mex/eepacc_mex_common.h)
     ARR("s_speedLim", S.s_speedLim, S.n_speedLim); ARR("v_speedLim", S.v_speedLim, n);
+    if (n != S.n_speedLim || n < 1 || !S.s_speedLim) return false;
     ARR("s_curv", S.s_curv, S.n_curv); ARR("curvature", S.curvature, n);
+    if (n != S.n_curv || n < 1 || !S.s_curv) return false;
     ARR("s_slope", S.s_slope, S.n_slope); ARR("slope", S.slope, n);
+    if (n != S.n_slope || n < 1 || !S.s_slope) return false;
     ARR("stopLoc", S.stopLoc, S.n_stop);
-    ARR("TLLoc", S.TLLoc, n); S.n_TL = n / 4;
+    ARR("TLLoc", S.TLLoc, n);
+    if (n % 4 != 0) return false;
+    S.n_TL = n / 4;
     REQ("stopRefDist", S.stopRefDist); REQ("stopRefVelSlope", S.stopRefVelSlope); REQ("stopVel", S.stopVel);
     REQ("TLstopVel", S.TLstopVel); REQ("TLStopRegionSize", S.TLStopRegionSize); REQ("alpha_TTL", S.alpha_TTL);
     eepacc_vehicle& V = c.V;

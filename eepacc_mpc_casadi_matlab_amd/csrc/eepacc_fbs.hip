@@ -1656,6 +1656,7 @@ k_fbs_run(fbs_run_args a) {
             while (__hip_atomic_load(&a.done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
                 __builtin_amdgcn_s_sleep(32);
                 if (++spins > a.spin_limit) { failed = true; break; }
+                if ((spins & 63) == 0 && __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1665,7 +1666,7 @@ k_fbs_run(fbs_run_args a) {
                 if (failed) atomicOr(a.err_word, 1);
                 for (int kk = kk0; kk < kk1; ++kk) a.status[(size_t)kk * B + b] = 3;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(&a.done[b], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(&a.done[b], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             continue;
         }
@@ -1732,7 +1733,7 @@ k_fbs_run(fbs_run_args a) {
         if (lane == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&a.done[b], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&a.done[b], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -20,7 +20,7 @@ import numpy as np
 
 from ._abi import Vehicle, make_vehicle
 
-__all__ = ["pwa", "build_tables", "NlpEvaluator", "NlpSolver", "RunOpt_NLP", "car_following_start", "nlp_rows", "postprocess", "riccati_batched"]
+__all__ = ["pwa", "build_tables", "pick_start", "NlpEvaluator", "NlpSolver", "RunOpt_NLP", "car_following_start", "nlp_rows", "postprocess", "riccati_batched"]
 
 
 def pwa(x, xs, ys):
@@ -725,6 +725,21 @@ def car_following_start(OPTsettings: Dict[str, Any], V: Dict[str, float], tables
     return out[0] if single else out
 
 
+def pick_start(J, status, e_prim, feas_tol: float = 1e-6):
+    """Winning start of every route, [R][S] tensors -> [R] indices, in tiers: the lowest objective among the starts at a
+    KKT point (status 0); if a route has none, the lowest objective among its primal-feasible starts (constraint
+    violation e_prim <= feas_tol); if none of those either, the smallest violation."""
+    import torch
+    inf = torch.full_like(J, float("inf"))
+    Jn = torch.where(torch.isfinite(J), J, inf)
+    tier1 = torch.where(status == 0, Jn, inf)
+    tier2 = torch.where(e_prim <= feas_tol, Jn, inf)
+    has1 = torch.isfinite(tier1).any(dim=1)
+    has2 = torch.isfinite(tier2).any(dim=1)
+    viol = torch.where(torch.isfinite(e_prim), e_prim, inf)
+    return torch.where(has1, tier1.argmin(dim=1), torch.where(has2, tier2.argmin(dim=1), viol.argmin(dim=1)))
+
+
 def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500,
                  fused: bool = False, restarts: int = 3):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
@@ -747,8 +762,7 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
     # restarts = 3: with the re-centring restoration a start reaches the saved ABO solution in either arithmetic
     R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused, restarts=restarts)
     st = R["status"].view(Rn, S)
-    J = torch.where(st == 0, R["J"].view(Rn, S), R["J"].view(Rn, S) + 1e30)       # a KKT point beats any unfinished start
-    win = J.argmin(dim=1)
+    win = pick_start(R["J"].view(Rn, S), st, R["kkt"][:, 1].view(Rn, S))
     idx = torch.arange(Rn, device=win.device) * S + win
     return dict(J=R["J"][idx], status=R["status"][idx], iters=R["iters"][idx], start=win, chi=R["chi"][idx], u=R["u"][idx],
                 all_J=R["J"].view(Rn, S), all_status=st)

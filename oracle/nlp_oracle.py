@@ -44,7 +44,7 @@ ISO_AMAX = np.array([5.0, 5.0, 3.5, 3.5])
 ISO_JMAG = np.array([5.0, 5.0, 2.5, 2.5])
 
 
-from eepacc_mpc_casadi_matlab_amd.nlp import pwa, build_tables   # host preprocessing of RunOpt_NLP.m:63-184 (shared, pinned on the saved tables)
+from .nlp_tables import lookup as pwa, build_tables   # the checker's own restatement of RunOpt_NLP.m:63-184 (no product code)
 
 
 def pwa_smooth(x, xs, ys, eps):

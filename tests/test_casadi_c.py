@@ -73,6 +73,38 @@ def test_function_table_like_casadi_fun_c_reads_it(lib, tmp_path):
     assert lib.casadi_c_n_loaded() == 0 and lib.casadi_c_id(b"eepacc_ab_step") < 0
 
 
+def test_malformed_settings_files_are_refused(lib, tmp_path):
+    """paired route tables of different lengths, a TLLoc that is not a multiple of four, an empty required table: the
+    settings-file reader refuses them (as the MEX reader does) instead of reading past the shorter array"""
+    OPT, V, _, _ = make_case("ABO", 20, stopLoc=np.array([300.0]), TLLoc=np.array([[800.0, 5.0, 20.0, 30.0]]))
+    good = str(tmp_path / "good.cfg")
+    write_config(good, OPT, V)
+    assert lib.casadi_c_push_file(good.encode()) == 0
+    lib.casadi_c_pop()
+    text = open(good).read().splitlines()
+
+    def variant(name, edit):
+        out = []
+        for line in text:
+            key = line.split(" ", 1)[0]
+            out.extend(edit(key, line))
+        path = str(tmp_path / (name + ".cfg"))
+        open(path, "w").write("\n".join(out) + "\n")
+        return path.encode()
+    drop_last = lambda line: " ".join(line.split(" ")[:-1])
+    cases = {
+        "short_v_speedLim": lambda k, l: [drop_last(l)] if k == "v_speedLim" else [l],
+        "short_curvature": lambda k, l: [drop_last(l)] if k == "curvature" else [l],
+        "short_slope": lambda k, l: [drop_last(l)] if k == "slope" else [l],
+        "tlloc_not_x4": lambda k, l: [drop_last(l)] if k == "TLLoc" else [l],
+        "no_s_speedLim": lambda k, l: [] if k == "s_speedLim" else [l],
+        "gearbox_wrong_size": lambda k, l: [drop_last(l)] if k == "vehicle.tau_gb" else [l],
+    }
+    for name, edit in cases.items():
+        assert lib.casadi_c_push_file(variant(name, edit)) != 0, name
+        assert lib.casadi_c_n_loaded() == 0, name
+
+
 @pytest.mark.gpu
 def test_eval_equals_step_operators(lib, tmp_path):
     """mdlStart / mdlOutputs / mdlTerminate of ABO/casadi_fun.c:150-190 against Engine.ab_step / fb_step."""

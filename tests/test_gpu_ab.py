@@ -146,11 +146,13 @@ def test_closed_loop_s2_vs_oracle(torch_mod, lead_trace):
             assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * TOL[n], (i, n)
 
 
-def test_full_size_batch_properties(torch_mod, lead_trace):
-    """BASELINE config 2 size (N=30, batch 4096): size-independent properties."""
+@pytest.mark.parametrize("N,B", [(30, 4096), (60, 8192)])
+def test_full_size_batch_properties(N, B, torch_mod, lead_trace):
+    """BASELINE config 2 size (N=30, batch 4096) and config 4's share of one GPU (N=60, 65536 / 8 = 8192 instances):
+    size-independent properties."""
     torch = torch_mod
-    OPT, V, _, _ = make_case("ABO", 30)
-    B, n_steps = 4096, 40
+    OPT, V, _, _ = make_case("ABO", N)
+    n_steps = 40
     sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"])
     eng = _engine(OPT, V, B)
     traj, status = eng.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])

@@ -329,36 +329,54 @@ def test_runopt_mirrors_return_the_reference_struct(torch_mod):
     assert set(("cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f")) <= set(sol)
 
 
+def _oracle_fb_runs(OPT, V, sc, n_steps, B):
+    """The oracle's closed loops of B scenarios side by side (ctypes releases the GIL; the oracle keeps no global state)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import Oracle
+    orcs = [Oracle(OPT, V) for _ in range(B)]
+
+    def one(i):
+        return orcs[i].run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())[:2]
+    with ThreadPoolExecutor(max_workers=min(B, 8)) as ex:
+        return list(ex.map(one, range(B)))
+
+
 def test_fb_estimator_modes(torch_mod, lead_trace):
     """FBMPC with the constant-velocity estimators (0) and the shifted previous solution (2,
-    EstimateVehicleTrajectory.m:81-88) against the oracle closed loop."""
-    from oracle import Oracle
+    EstimateVehicleTrajectory.m:81-88) against the oracle closed loop; the scenarios (close following, following at a
+    distance, free driving) are feasible throughout on the oracle's side, so every step is compared."""
     for est in (dict(paramEstSetting=0, TVestSetting=0), dict(paramEstSetting=2)):
         OPT, V, _, _ = make_case("ABO", 20, **est)
         B, n_steps = 3, 30
         sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=5)
-        sc["s_tv"] = sc["s_tv"] + np.array([0.0, 40.0, 500.0])[None, :]
+        sc["s_tv"] = sc["s_tv"] + np.array([15.0, 40.0, 500.0])[None, :]
         eng = _engine(OPT, V, 4)
         traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
         tr = traj.cpu().numpy(); st = status.cpu().numpy()
-        orc = Oracle(OPT, V)
-        for i in range(B):
-            ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
-            _compare_fb(tr[:, :, i], st[:, i], ref, rst, scale=10.0)
+        compared = 0
+        for i, (ref, rst) in enumerate(_oracle_fb_runs(OPT, V, sc, n_steps, B)):
+            compared += _compare_fb(tr[:, :, i], st[:, i], ref, rst, scale=10.0)
+        assert compared == B * n_steps, (est, compared)
 
 
 def test_fb_long_horizon_n60(torch_mod, lead_trace):
-    """FBMPC at the long horizon of BASELINE config 4 (N=60: 360 variables, 1562 rows)."""
-    from oracle import Oracle
+    """FBMPC at the long horizon of BASELINE config 4 (N=60: 360 variables, 1562 rows): 8 S2 scenarios x 20 steps
+    against the oracle's closed loops (one of them runs into an infeasible state at step 6 on both sides: 146 of the
+    160 steps are comparable, all of them are compared)."""
     OPT, V, _, _ = make_case("ABO", 60)
-    B, n_steps = 2, 4
+    B, n_steps = 8, 20
     sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=11)
-    eng = _engine(OPT, V, 2)
+    eng = _engine(OPT, V, B)
     traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    eng.synchronize()
     tr = traj.cpu().numpy(); st = status.cpu().numpy()
-    orc = Oracle(OPT, V)
-    ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][0]), 0.0, sc["s_tv"][:, 0].copy(), sc["v_tv"][:, 0].copy())
-    _compare_fb(tr[:, :, 0], st[:, 0], ref, rst, scale=10.0)
+    traj2, status2 = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    eng.synchronize()
+    assert np.array_equal(traj2.cpu().numpy(), tr) and np.array_equal(status2.cpu().numpy(), st)
+    compared = 0
+    for i, (ref, rst) in enumerate(_oracle_fb_runs(OPT, V, sc, n_steps, B)):
+        compared += _compare_fb(tr[:, :, i], st[:, i], ref, rst, scale=10.0)
+    assert compared >= 0.9 * B * n_steps, compared          # oracle: 146 of 160
 
 
 def test_fb_move_blocking(torch_mod, lead_trace):
@@ -381,14 +399,15 @@ def test_fb_move_blocking(torch_mod, lead_trace):
 
 @pytest.mark.parametrize("N", [2, 5])
 def test_fb_short_horizons(N, torch_mod, lead_trace):
-    from oracle import Oracle
+    """Horizons of 2 and 5 stages; the four scenarios stay feasible on the oracle's side, so all 48 steps are compared."""
     OPT, V, _, _ = make_case("ABO", N)
-    B, n_steps = 2, 8
-    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=4)
-    eng = _engine(OPT, V, 2)
+    B, n_steps = 4, 12
+    sc = make_s2(B, n_steps, lead_trace["V_TO_2Hz"], seed=6)
+    sc["s_tv"] = sc["s_tv"] + np.array([0.0, 12.0, 0.0, 0.0])[None, :]
+    eng = _engine(OPT, V, B)
     traj, status = eng.run_fbmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
     tr = traj.cpu().numpy(); st = status.cpu().numpy()
-    orc = Oracle(OPT, V)
-    for i in range(B):
-        ref, rst, _ = orc.run("fb", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
-        _compare_fb(tr[:, :, i], st[:, i], ref, rst, scale=10.0)
+    compared = 0
+    for i, (ref, rst) in enumerate(_oracle_fb_runs(OPT, V, sc, n_steps, B)):
+        compared += _compare_fb(tr[:, :, i], st[:, i], ref, rst, scale=10.0)
+    assert compared == B * n_steps, compared

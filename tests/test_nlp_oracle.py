@@ -66,6 +66,58 @@ def test_pwa_tables_with_route_features():
     assert P.n_rows == 17 + 2 + 10
 
 
+def _feature_routes():
+    """Routes that put every branch of the table preprocessing in play: speed-limit steps up and down (slopes to
+    saturate, crossings to fix), curves that undercut the speed limit, two stops closer than stopRefDist, traffic
+    lights, a slope, and the reference's use cases 3, 6, 11, 12 (GetUseCase.m)."""
+    from eepacc_mpc_casadi_matlab_amd.settings import Settings, default_opt
+    custom = dict(speedLimZones=np.array([[60.0, 0.0], [30.0, 300.0], [100.0, 420.0], [50.0, 1000.0], [80.0, 1010.0]]),
+                  curves=np.array([[-1 / 20, 100, 130], [1 / 40, 170, 230], [-1 / 80, 230, 250], [1 / 15, 990, 1030]]),
+                  slopes=np.array([[2.0, 100, 400], [-3.0, 700, 900]]),
+                  stopLoc=np.array([400.0, 450.0, 1500.0]),
+                  TLLoc=np.array([[800.0, 5.0, 20.0, 30.0], [1200.0, 0.0, 15.0, 10.0]]))
+    o = default_opt(); o.update(custom)
+    yield "custom", Settings(o, tree="ABO", N_hor=20)
+    for case in (3, 6, 11, 12):
+        o = default_opt(); o["useCaseNum"] = case
+        yield "usecase%d" % case, Settings(o, tree="ORIG", N_hor=20)
+
+
+def test_product_table_preprocessing_equals_the_oracles_restatement():
+    """build_tables of the product (eepacc_mpc_casadi_matlab_amd/nlp.py) against the oracle's own line-by-line
+    restatement of RunOpt_NLP.m:63-184 + minPWA / SaturateSlopePWA / FixCrossingPWA / SimplifyPWA / InterpPWA
+    (oracle/nlp_tables.py; no shared code) on routes with every table in play; and both lookups on a grid."""
+    from eepacc_mpc_casadi_matlab_amd import nlp as product
+    from oracle import nlp_tables as checker
+    n_knots = 0
+    for name, OPT in _feature_routes():
+        Tp, Tc = product.build_tables(OPT), checker.build_tables(OPT)
+        assert Tp["N"] == Tc["N"] and Tp["flat"] == Tc["flat"], name
+        for key in ("slope", "vlim", "curv", "stop", "vinc"):
+            for a, b in zip(Tp[key], Tc[key]):
+                assert a.shape == b.shape, (name, key, a.shape, b.shape)
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg="%s %s" % (name, key))
+        for key in ("tl_s", "tl_v", "tl_state"):
+            np.testing.assert_array_equal(Tp[key], Tc[key], err_msg="%s %s" % (name, key))
+        n_knots += len(Tc["vinc"][0])
+        x = np.linspace(Tc["vinc"][0][0] - 50.0, Tc["vinc"][0][-1] + 50.0, 4001)
+        for a, b in zip(product.pwa(x, *Tp["vinc"]), checker.lookup(x, *Tc["vinc"])):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    assert n_knots > 40                                            # the incentive tables are not trivial
+
+
+def test_oracle_does_not_import_the_products_solver_or_tables():
+    """oracle/ may use the product's ABI mirror (struct layouts) but none of its algorithms."""
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            for line in open(os.path.join(root, fn)):
+                m = re.match(r"\s*(from|import)\s+eepacc_mpc_casadi_matlab_amd(\.\w+)*", line)
+                if m:
+                    assert "._abi" in line, (fn, line.strip())
+
+
 @pytest.mark.parametrize("eps", [(0.0, 0.0), (3.0, 1.5)])
 def test_derivatives_against_finite_differences(eps):
     """eps > 0: the graduated smoothing of the lookups the solver may use (value, slope and curvature of the
@@ -189,3 +241,14 @@ def test_host_start_generator_matches_the_oracle_start():
         # the start keeps v >= 0 and stays behind the lead vehicle; the hard row s <= s_tv - h_min may be missed by the
         # braking overshoot of the heuristic (measured: 0.6 m), which the solver treats as a row that does not hold yet
         assert chi[:, 1].min() > -1e-9 and (chi[1:, 0] - (stv[i] - P.h_min)).max() < 1.0
+
+
+def test_start_selection_tiers():
+    """nlp.pick_start: KKT points first (lowest objective), then primal-feasible unfinished starts (lowest objective),
+    then the smallest constraint violation -- never a tie broken by position (round 2: J + 1e30 absorbed J)."""
+    import torch
+    from eepacc_mpc_casadi_matlab_amd.nlp import pick_start
+    J = torch.tensor([[3.2e5, 1.1e5, 2.0e5], [3.2e5, 1.1e5, 2.0e5], [5.0, 4.0, 3.0], [1.0, float("nan"), 2.0]], dtype=torch.float64)
+    st = torch.tensor([[1, 2, 1], [1, 2, 0], [1, 1, 1], [0, 0, 0]], dtype=torch.int32)
+    ep = torch.tensor([[1e-9, 1e-8, 1e-9], [1e-9, 1e-8, 1e-9], [1e-2, 1e-3, 1e-1], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    assert pick_start(J, st, ep).tolist() == [1, 2, 1, 0]
