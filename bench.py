@@ -51,8 +51,8 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))        # a one-GPU box offers 16 host cores to the job
-    n_all = min(4 * cores, sc["v0"].shape[0])
+    cores = max(1, cores)                 # every core of the affinity mask (a one-GPU box offers 16 of the host's 256)
+    n_all = min(2 * cores, sc["v0"].shape[0])
     t1 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         done_all = sum(ex.map(one, range(n_all)))
@@ -60,17 +60,53 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
     return dict(value=done / dt, unit="QP steps/s", cores=1, kind="port",
                 sample="%d S2 instances x %d closed-loop %sMPC steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
                        % (n_inst, n_steps, "BL" if OPT.get("bl_mode") else kind.upper(), OPT["N_hor"]),
-                all_cores={"value": done_all / dt_all, "cores": cores,
+                all_cores={"value": done_all / dt_all, "cores": cores, "cores_source": "len(os.sched_getaffinity(0))",
                            "sample": "%d instances x %d steps, one instance per thread" % (n_all, n_steps)})
 
 
-def profile_figures(fb: bool, N: int):
-    """Per-QP-step figures of the dominant kernel from the committed PMC profile of this command."""
-    path = os.path.join(ROOT, "profiles", "r02_%s_N%d_summary.json" % ("fb" if fb else "ab", N))
-    try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
-    except Exception:
-        return None, os.path.relpath(path, ROOT)
+def source_hash():
+    """Hash of the kernel sources the running library was built from (the profile tooling stores the same value)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "eepacc_mpc_casadi_matlab_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_figures(workload: str, N: int, driver_style: bool = False):
+    """Per-QP-step figures of the dominant kernel from the committed PMC profile of this command: the newest round's
+    summary for (workload, horizon[, the driver's short launch]).  Returns (summary | None, path, stale note | None):
+    a summary taken on other kernel sources or build flags than the running library is still used (the flop count per
+    QP step moves by a few per cent between kernel revisions) but flagged in the JSON line."""
+    tag = {"abmpc": "ab", "fbmpc": "fb", "blmpc": "bl"}[workload]
+    cands = []
+    for rnd in ("r03", "r02"):
+        if driver_style:
+            cands.append("%s_%s_N%d_driver_summary.json" % (rnd, tag, N))
+        cands.append("%s_%s_N%d_summary.json" % (rnd, tag, N))
+    for name in cands:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            prof = json.load(open(path))
+        except Exception:
+            continue
+        stale = None
+        want = prof.get("source_hash")
+        if want is None:
+            stale = "profile predates source hashing (round 2 kernels)"
+        elif want != source_hash():
+            stale = "profile taken on kernel sources %s, running %s" % (want, source_hash())
+        try:
+            from eepacc_mpc_casadi_matlab_amd import engine
+            flags = engine.load_library().eepacc_build_flags().decode()
+            if prof.get("build_flags", "") != flags:
+                stale = (stale + "; " if stale else "") + "build flags differ (%r vs %r)" % (prof.get("build_flags", ""), flags)
+        except Exception:
+            pass
+        return prof, os.path.relpath(path, ROOT), stale
+    return None, "profiles/r03_%s_N%d_summary.json" % (tag, N), None
 
 
 def build_parser():
@@ -86,23 +122,21 @@ def build_parser():
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (FBMPC, N=60, baseline controller, a few NLP routes) that the default "
+                         "single-GPU headline command appends under \"secondary\"")
     return ap
 
 
-def run_bench(args, make_engine=None, device=None, backend=None):
-    """The benchmark job of one rank.  make_engine(OPT, V, device, B) builds the engine (default: the HIP engine);
-    device / backend let the CPU test drive the same flow over gloo with a stand-in engine.  Returns the result
-    dict on rank 0, None on the other ranks."""
+def dist_setup(device=None, backend=None):
+    """Rank, device and process group of this process -- shared by every workload.  One rank per GPU over RCCL ("nccl");
+    EEPACC_DIST_BACKEND=gloo rehearses the multi-rank flow on fewer GPUs than ranks (ranks then share devices round-robin
+    and the small result tensors are reduced on the host).  The process group is initialised before anything else
+    touches the GPU.  Returns (rank, world, local_rank, backend, on_gpu, n_dev, dev, torch device)."""
     import torch
     import torch.distributed as dist
-    from conftest import make_case
-    from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
-    from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
-    from eepacc_mpc_casadi_matlab_amd.distributed import (rank_world, shard_range, local_kpis, reduce_kpis, kpi_dict,
-                                                          max_over_ranks)
+    from eepacc_mpc_casadi_matlab_amd.distributed import rank_world
     rank, world, local_rank = rank_world()
-    # one rank per GPU over RCCL ("nccl"); EEPACC_DIST_BACKEND=gloo rehearses the multi-rank flow on fewer
-    # GPUs than ranks (ranks then share devices round-robin and the KPI tensors are reduced on the host)
     backend = backend or os.environ.get("EEPACC_DIST_BACKEND", "nccl")
     on_gpu = device is None
     if on_gpu:
@@ -119,6 +153,20 @@ def run_bench(args, make_engine=None, device=None, backend=None):
             dist.init_process_group("nccl", device_id=d)
         else:
             dist.init_process_group(backend)
+    return rank, world, local_rank, backend, on_gpu, n_dev, dev, d
+
+
+def run_bench(args, make_engine=None, device=None, backend=None):
+    """The benchmark job of one rank.  make_engine(OPT, V, device, B) builds the engine (default: the HIP engine);
+    device / backend let the CPU test drive the same flow over gloo with a stand-in engine.  Returns the result
+    dict on rank 0, None on the other ranks."""
+    import torch
+    import torch.distributed as dist
+    from conftest import make_case
+    from eepacc_mpc_casadi_matlab_amd.scenarios import make_s2
+    from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
+    from eepacc_mpc_casadi_matlab_amd.distributed import shard_range, local_kpis, reduce_kpis, kpi_dict, max_over_ranks
+    rank, world, local_rank, backend, on_gpu, n_dev, dev, d = dist_setup(device, backend)
     fb = args.workload == "fbmpc"
     bl = args.workload == "blmpc"
     K, W = args.steps, args.warmup
@@ -219,12 +267,14 @@ def run_bench(args, make_engine=None, device=None, backend=None):
         launch_s = (kernel_ms / 1e3) / launches
         qp_per_launch = B * (K / launches)
         qp_rate = qp_per_launch / launch_s                                         # QP steps/s of this rank's kernel
-        prof, prof_path = profile_figures(fb, N) if not bl else (None, "none: the baseline variant is not profiled separately")
+        driver_style = K / launches <= 40
+        prof, prof_path, stale = profile_figures(args.workload, N, driver_style)
         kname = "k_fbs_run" if fb else "k_run_abmpc"
         if prof is not None:
             ps = prof["per_qp_step"]
             flops = ps["fp64_flops_active_lanes"]
             achieved = flops * qp_rate / 1e12
+            dv = prof["derived"]
             roof = {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_VALU_TFLOPS,
                     "traffic": ps["hbm_bytes_fetch_plus_write"] * qp_per_launch,
@@ -235,10 +285,18 @@ def run_bench(args, make_engine=None, device=None, backend=None):
                                   "this run) against the vector-fp64 peak; HBM does not bind (compulsory traffic ~%d B per QP step) and "
                                   "the kernel has no dense contraction for MFMA" % (prof_path, ps["active_lane_fraction"], flops, bytes_fused),
                     "kernel": kname, "launches": launches, "launch_ms": launch_s * 1e3,
-                    "valu_issue_util": prof["derived"]["valu_issue_util"],
+                    "valu_issue_util": dv["valu_issue_util"],
                     "fp64_pipe_util_all_lanes": ps["fp64_flops_all_lanes"] * qp_rate / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                    "wave_cycles_waiting": prof["derived"]["wave_cycles_waiting"],
-                    "occupancy_waves_per_simd": prof["derived"]["waves_per_simd"]}
+                    "wave_cycles_waiting": dv["wave_cycles_waiting"],
+                    "occupancy_waves_per_simd": dv["waves_per_simd"],
+                    # what actually limits the kernel: every resident wave is issuing an instruction
+                    # for `wave_cycles_issuing_any` of its lifetime, so with w waves per SIMD the SIMD's issue port is taken
+                    # for w x that share; only `fp64_share_of_valu` of the vector instructions are fp64 arithmetic
+                    "simd_issue_busy": (dv.get("wave_cycles_issuing_any") or 0.0) * dv["waves_per_simd"],
+                    "fp64_share_of_valu": (ps["fp64_add_wave_insts"] + ps["fp64_mul_wave_insts"] + ps["fp64_fma_wave_insts"]) / ps["valu_wave_insts"],
+                    "profile": prof_path}
+            if stale:
+                roof["profile_stale"] = stale
         else:
             roof = {"bound": "valu_fp64", "achieved": None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None,
                     "traffic": None, "definition": "no committed PMC profile for this workload (%s)" % prof_path,
@@ -275,61 +333,119 @@ def run_bench(args, make_engine=None, device=None, backend=None):
     return res
 
 
-def run_nlp_bench(args):
+def _compact(res):
+    """The part of a result line a secondary entry keeps."""
+    r = res["roofline"]
+    keep = {k: res[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
+    keep["config"] = res["config"]["workload"]
+    keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms",
+                                              "simd_issue_busy", "occupancy_waves_per_simd", "profile", "profile_stale") if k in r}
+    keep["solver"] = {k: res["solver"][k] for k in ("mean_active_set_iterations_per_step", "bad_exits", "bad_exits_with_infeasible_measured_state")}
+    return keep
+
+
+def secondary_measurements(args):
+    """BASELINE configs 3-5 (and the baseline controller) measured in the same process AFTER the headline's clock stopped
+    (default command, one rank): short launches of the driver's own shape so the whole command stays within minutes."""
+    import copy
+    out = {}
+    plan = [("fbmpc_N30_b4096", dict(workload="fbmpc", horizon=30, batch=4096)),                # BASELINE configs[2]
+            ("abmpc_N60_b8192", dict(workload="abmpc", horizon=60, batch=8192)),                # configs[3]: 65536 / 8 per GPU
+            ("blmpc_N30_b4096", dict(workload="blmpc", horizon=30, batch=4096))]
+    for name, kw in plan:
+        a = copy.copy(args)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        a.no_cpu_baseline = True
+        a.chunk = 0
+        t0 = time.perf_counter()
+        try:
+            out[name] = _compact(run_bench(a))
+            out[name]["wall_s_incl_setup"] = time.perf_counter() - t0
+        except Exception as e:                                    # a secondary entry never takes the headline down
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        a = copy.copy(args)
+        a.workload, a.batch, a.steps, a.warmup = "nlp", NLP_SECONDARY_ROUTES, 1, 0
+        t0 = time.perf_counter()
+        r = run_nlp_bench(a)
+        out["nlp_%droutes" % NLP_SECONDARY_ROUTES] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "solver", "reference")}
+        out["nlp_%droutes" % NLP_SECONDARY_ROUTES]["wall_s_incl_setup"] = time.perf_counter() - t0
+    except Exception as e:
+        out["nlp_%droutes" % NLP_SECONDARY_ROUTES] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+NLP_SECONDARY_ROUTES = 4            # BASELINE configs[4] asks 128 routes per GPU; the default command's budget fits this many
+
+
+NLP_STARTS = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
+
+
+def nlp_traces(OPT, lead, rank, Rn):
+    """Per-route lead vehicle of BASELINE configs[4]: the cycle's speeds scaled by U(0.9, 1.1) (seed 100 + rank)."""
+    from eepacc_mpc_casadi_matlab_amd.settings import Run_DrivingCycle
+    rng = np.random.default_rng(100 + rank)
+    traces = []
+    for f in rng.uniform(0.9, 1.1, Rn):
+        s_tv, _ = Run_DrivingCycle(OPT, V_TO_resampled=lead["V_TO_2Hz"] * f)
+        traces.append(s_tv - OPT["TVlength"])
+    return np.stack(traces)
+
+
+def run_nlp_bench(args, make_solver=None, device=None, backend=None):
     """BASELINE configs[4]: RunOpt_NLP for `--batch` routes per GPU (the reference's 435 s scenario with the lead vehicle's
-    speed trace scaled per route), each solved from a cold start by the multi-start batch of nlp.solve_routes.  Routes shard
-    across ranks with no data-path collective; one all-reduce (SUM) of (routes at a KKT point, sum of objectives) at the end."""
+    speed trace scaled per route), each solved from a cold start by the multi-start batch.  Routes shard across ranks with
+    no data-path collective; one all-reduce (SUM) of (routes at a KKT point, sum of objectives, iterations) at the end.
+    make_solver(OPT, V, dev) -> callable(traces) -> dict(status, J, iters) (torch tensors, one entry per route): default is
+    the HIP solver; the CPU test drives the same flow over gloo with a stand-in."""
     import torch
     import torch.distributed as dist
-    from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver, solve_routes
-    from eepacc_mpc_casadi_matlab_amd.settings import Run_DrivingCycle
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_case
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from eepacc_mpc_casadi_matlab_amd.distributed import max_over_ranks
+    rank, world, local_rank, backend, on_gpu, n_dev, dev, d = dist_setup(device, backend)
     K = args.steps if args.steps != 200 else 1
     W = args.warmup if args.warmup != 200 else 0
     Rn = args.batch if args.batch != 4096 else 128
     OPT, V, _, _ = make_case("ABO")
     lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
-    rng = np.random.default_rng(100 + rank)
-    traces = []
-    for f in rng.uniform(0.9, 1.1, Rn):                                   # per-route lead vehicle: the cycle's speeds scaled
-        s_tv, _ = Run_DrivingCycle(OPT, V_TO_resampled=lead["V_TO_2Hz"] * f)
-        traces.append(s_tv - OPT["TVlength"])
-    traces = np.stack(traces)
-    sol = NlpSolver(OPT, V, device=local)
-    starts = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
+    traces = nlp_traces(OPT, lead, rank, Rn)
+    if make_solver is None:
+        def make_solver(OPT_, V_, dev_):
+            from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver, solve_routes
+            sol = NlpSolver(OPT_, V_, device=dev_)
+            return lambda tr: solve_routes(sol, OPT_, V_, tr, NLP_STARTS, max_iter=int(OPT_.get("NLPmaxIter", 600)))
+    solve = make_solver(OPT, V, dev)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
     for _ in range(W):
-        solve_routes(sol, OPT, V, traces, starts, max_iter=600)
-    torch.cuda.synchronize()
+        solve(traces)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(K):
-        R = solve_routes(sol, OPT, V, traces, starts, max_iter=600)
-    torch.cuda.synchronize()
+        R = solve(traces)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    kp = torch.stack([(R["status"] == 0).sum().double(), R["J"].sum(), R["iters"].double().sum()])
+    sync()
+    dt = max_over_ranks(time.perf_counter() - t0, world, d if backend == "nccl" else None)
+    kp = torch.stack([(R["status"] == 0).sum().double(), R["J"].double().sum(), R["iters"].double().sum()])
+    kp = kp if (backend == "nccl" or not on_gpu) else kp.cpu()
     if world > 1:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
     if rank != 0:
         return None
     total = world * Rn * K
-    return {"metric": "RunOpt_NLP routes solved/s (whole node), 435 s route = 870 intervals, cold start", "value": total / float(dt),
-            "unit": "routes/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": float(dt) * 1e3 / K,
+    return {"metric": "RunOpt_NLP routes solved/s (whole node), 435 s route = 870 intervals, cold start", "value": total / dt,
+            "unit": "routes/s", "n_gpus": min(world, n_dev) if on_gpu else 0, "ranks": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "RunOpt_NLP, %d routes per GPU x %d starts, 870 intervals, lead trace scaled per route" % (Rn, len(starts)),
-                       "routes_per_gpu": Rn, "starts_per_route": len(starts)},
+            "config": {"workload": "RunOpt_NLP, %d routes per GPU x %d starts, 870 intervals, lead trace scaled per route" % (Rn, len(NLP_STARTS)),
+                       "routes_per_gpu": Rn, "starts_per_route": len(NLP_STARTS)},
             "solver": {"routes_at_kkt_point": int(kp[0].item()), "routes": world * Rn, "mean_iterations": float(kp[2].item()) / (world * Rn),
                        "sum_objective": float(kp[1].item())},
             "reference": {"ipopt_tSolve_s_one_route": 190.4754463, "source": "ABO/savedNLPsol.mat (NLPsol.tSolve), other hardware"}}
@@ -339,6 +455,9 @@ def main():
     args = build_parser().parse_args()
     import torch.distributed as dist
     res = run_nlp_bench(args) if args.workload == "nlp" else run_bench(args)
+    if (res is not None and args.workload == "abmpc" and not args.no_secondary and res.get("ranks") == 1 and res.get("n_gpus") == 1
+            and args.horizon == 30 and args.batch == 4096):
+        res["secondary"] = secondary_measurements(args)
     if res is not None:
         print(json.dumps(res))
     if dist.is_initialized():

@@ -95,6 +95,52 @@ def test_two_rank_job_equals_single_process():
     assert k2["a_max"] >= k2["a_min"] and k2["j_max"] >= k2["j_min"]
 
 
+def _nlp_stand_in(OPT, V, dev):
+    """Deterministic stand-in for the route solver: status / objective / iterations are functions of the lead trace alone,
+    so the union of two shards must reduce to the same totals as ... the two shards."""
+    def solve(traces):
+        tr = torch.from_numpy(np.asarray(traces))
+        J = tr[:, -1] * 1e3 + tr[:, 100]
+        return dict(status=(tr[:, -1] > 3050.0).to(torch.int32), J=J, iters=(tr[:, 50] % 7).to(torch.int32) + 10)
+    return solve
+
+
+def _nlp_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    args = types.SimpleNamespace(workload="nlp", steps=2, warmup=1, batch=3, horizon=30, chunk=0, no_cpu_baseline=True, gpus=world)
+    res = bench.run_nlp_bench(args, make_solver=_nlp_stand_in, device=torch.device("cpu"), backend="gloo")
+    if rank == 0:
+        json.dump(res, open(os.path.join(outdir, "nlp.json"), "w"))
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_nlp_job_reduces_the_route_outcomes():
+    """bench.run_nlp_bench (BASELINE configs[4]) over two gloo ranks: same rank / device / process-group set-up as
+    run_bench (bench.dist_setup), routes sharded by rank (seed 100 + rank), one SUM all-reduce of the outcome."""
+    import socket
+    import bench
+    from conftest import make_case
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_nlp_worker, args=(2, port, d), nprocs=2, join=True)
+        two = json.load(open(os.path.join(d, "nlp.json")))
+    assert two["ranks"] == 2 and two["solver"]["routes"] == 6 and two["config"]["routes_per_gpu"] == 3 and two["scaling"] == "weak"
+    OPT, V, _, _ = make_case("ABO")
+    lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
+    kkt = 0; J = 0.0; it = 0.0
+    for rank in (0, 1):
+        R = _nlp_stand_in(OPT, V, 0)(bench.nlp_traces(OPT, lead, rank, 3))
+        kkt += int((R["status"] == 0).sum()); J += float(R["J"].sum()); it += float(R["iters"].sum())
+    assert two["solver"]["routes_at_kkt_point"] == kkt
+    assert two["solver"]["sum_objective"] == pytest.approx(J, rel=1e-12)
+    assert two["solver"]["mean_iterations"] == pytest.approx(it / 6, rel=1e-12)
+
+
 def test_local_kpis_against_report():
     """local_kpis / kpi_dict (the reduction's inputs) reproduce the single-vehicle key figures of report.kpi_report
     (Main.m:203-263) on the saved ABMPC solution."""

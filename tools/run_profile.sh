@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 W=/tmp/prof_$TAG
 rm -rf $W; mkdir -p $OUT $W
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --workload $WL --no-cpu-baseline $*"
+B="$ROOT/bench.py --workload $WL --no-cpu-baseline --no-secondary $*"
 run() {   # name, rocprof args...
     local name=$1; shift
     rocprofv3 "$@" --output-format csv -d $W/$name -- python3 $B > $OUT/bench_$name.json 2> $OUT/$name.err
