@@ -19,7 +19,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof_dir, name, kern, batch, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
 qp_steps = batch * steps
-out = {"name": name, "kernel": kern, "qp_steps_per_launch": qp_steps, "kernel_stats": [], "pmc": {}}
+sys.path.insert(0, ROOT)
+import bench as _bench                                             # noqa: E402  (source_hash of the kernel sources)
+out = {"name": name, "kernel": kern, "qp_steps_per_launch": qp_steps, "source_hash": _bench.source_hash(),
+       "build_flags": " ".join(os.environ.get("EEPACC_EXTRA_FLAGS", "").split()), "kernel_stats": [], "pmc": {}}
 
 
 def one(pattern):
@@ -84,6 +87,33 @@ if p:
         "wave_cycles_issuing_any": g("SQ_ACTIVE_INST_ANY") / wc if wc else None,
         "waves": g("SQ_WAVES"),
         "waves_per_simd": g("SQ_WAVES") / 1024.0,
+        # share of the SIMD's time in which one of its resident waves has an instruction in flight
+        "simd_issue_busy": (g("SQ_ACTIVE_INST_ANY") / wc) * (g("SQ_WAVES") / 1024.0) if wc else None,
     }
+    if g("SQ_ACTIVE_INST_LDS") or g("SQ_INSTS_VMEM_RD"):
+        # stall attribution.  ACTIVE_INST_* are per-wave quad-cycles with an instruction of that class in flight; the
+        # LEVEL counters integrate the number of outstanding instructions, so LEVEL / INSTS is a mean latency (cycles)
+        vm = g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")
+        out["stall_split"] = {
+            "active_valu": g("SQ_ACTIVE_INST_VALU") / wc if wc else None,
+            "active_scalar": g("SQ_ACTIVE_INST_SCA") / wc if wc else None,
+            "active_lds": g("SQ_ACTIVE_INST_LDS") / wc if wc else None,
+            "active_vmem": g("SQ_ACTIVE_INST_VMEM") / wc if wc else None,
+            "active_flat": g("SQ_ACTIVE_INST_FLAT") / wc if wc else None,
+            "active_misc": g("SQ_ACTIVE_INST_MISC") / wc if wc else None,
+            "wait_any": g("SQ_WAIT_ANY") / wc if wc else None,
+            "wait_inst_any": g("SQ_WAIT_INST_ANY") / wc if wc else None,
+            "wait_inst_lds": g("SQ_WAIT_INST_LDS") / wc if wc else None,
+            "per_qp_step": {"vmem_rd_insts": g("SQ_INSTS_VMEM_RD") / qp_steps, "vmem_wr_insts": g("SQ_INSTS_VMEM_WR") / qp_steps,
+                            "flat_insts": g("SQ_INSTS_FLAT") / qp_steps, "smem_insts": g("SQ_INSTS_SMEM") / qp_steps,
+                            "branch_insts": g("SQ_INSTS_BRANCH") / qp_steps, "lds_insts": g("SQ_INSTS_LDS") / qp_steps},
+            "mean_latency_cycles": {"vmem": g("SQ_INST_LEVEL_VMEM") / vm if vm else None,
+                                    "lds": g("SQ_INST_LEVEL_LDS") / g("SQ_INSTS_LDS") if g("SQ_INSTS_LDS") else None,
+                                    "smem": g("SQ_INST_LEVEL_SMEM") / g("SQ_INSTS_SMEM") if g("SQ_INSTS_SMEM") else None},
+            # serial exposure: instructions x mean latency per QP step, as a share of a wave's lifetime per QP step
+            "latency_cycles_per_qp_step": {"vmem": g("SQ_INST_LEVEL_VMEM") / qp_steps, "lds": g("SQ_INST_LEVEL_LDS") / qp_steps,
+                                           "smem": g("SQ_INST_LEVEL_SMEM") / qp_steps},
+            "wave_cycles_per_qp_step": 4.0 * wc / qp_steps,
+        }
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{name}_summary.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in out if k not in ("dispatches",)}, indent=1)[:4000])

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-3 profile set on the GPU box: default command and driver-style command of the three controllers + N = 60.
+#   tools/r03_profile_all.sh <suffix>
+SFX=$1
+cd ${GRAFT_REPO_ROOT:-.}
+tools/run_profile.sh ab30$SFX abmpc > gpurun_out/prof_ab30$SFX.log 2>&1
+tools/run_profile.sh fb30$SFX fbmpc > gpurun_out/prof_fb30$SFX.log 2>&1
+EEPACC_PROFILE_NO_DRIVER=1 tools/run_profile.sh ab30d$SFX abmpc --steps 20 --warmup 5 > gpurun_out/prof_ab30d$SFX.log 2>&1
+EEPACC_PROFILE_NO_DRIVER=1 tools/run_profile.sh fb30d$SFX fbmpc --steps 20 --warmup 5 > gpurun_out/prof_fb30d$SFX.log 2>&1
+EEPACC_PROFILE_NO_DRIVER=1 tools/run_profile.sh ab60d$SFX abmpc --horizon 60 --batch 8192 --steps 20 --warmup 5 > gpurun_out/prof_ab60d$SFX.log 2>&1
+EEPACC_PROFILE_NO_DRIVER=1 tools/run_profile.sh bl30d$SFX blmpc --steps 20 --warmup 5 > gpurun_out/prof_bl30d$SFX.log 2>&1
+ls gpurun_out | head -50
