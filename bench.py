@@ -414,7 +414,7 @@ def run_nlp_bench(args, make_solver=None, device=None, backend=None):
         def make_solver(OPT_, V_, dev_):
             from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver, solve_routes
             sol = NlpSolver(OPT_, V_, device=dev_)
-            return lambda tr: solve_routes(sol, OPT_, V_, tr, NLP_STARTS, max_iter=int(OPT_.get("NLPmaxIter", 600)))
+            return lambda tr: solve_routes(sol, OPT_, V_, tr, NLP_STARTS, max_iter=int(OPT_.get("NLPmaxIter", 5000)))
     solve = make_solver(OPT, V, dev)
 
     def sync():

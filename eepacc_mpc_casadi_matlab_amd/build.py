@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libeepacc.so")
 FLAGFILE = os.path.join(HERE, "libeepacc.flags")
-SOURCES = ["eepacc_kernels.hip", "eepacc_qp_dense.hip", "eepacc_fb.hip", "eepacc_fbs.hip", "eepacc_capi.cpp", "eepacc_casadi_c.cpp", "eepacc_nlp.hip"]
-HEADERS = ["eepacc_device.h", "eepacc_qp_dense.h", "eepacc_fb.h", "eepacc_stage.h", "eepacc_wave.h", "eepacc_fbs.h", "eepacc_ab_impl.inc", os.path.join("..", "..", "include", "eepacc.h"),
+SOURCES = ["eepacc_kernels.hip", "eepacc_qp_dense.hip", "eepacc_fb.hip", "eepacc_fbs.hip", "eepacc_capi.cpp", "eepacc_casadi_c.cpp", "eepacc_nlp.hip", "eepacc_nlp_tables.cpp"]
+HEADERS = ["eepacc_device.h", "eepacc_qp_dense.h", "eepacc_fb.h", "eepacc_stage.h", "eepacc_wave.h", "eepacc_fbs.h", "eepacc_ab_impl.inc", "eepacc_nlp_solve.inc", os.path.join("..", "..", "include", "eepacc.h"),
            os.path.join("..", "..", "include", "eepacc_casadi_c.h"), os.path.join("..", "..", "include", "eepacc_nlp.h")]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

@@ -236,9 +236,10 @@ __global__ void __launch_bounds__(64)
 k_riccati(int B, int N, const double* __restrict__ Qg, const double* __restrict__ qg, const double* __restrict__ ABg,
           const double* __restrict__ cg, const double* __restrict__ regg, const RicScale sc, double* __restrict__ dchi,
           double* __restrict__ du, double* __restrict__ nu, double* __restrict__ work, int32_t* __restrict__ status,
-          double* __restrict__ gnorm, const double* __restrict__ qlam) {
+          double* __restrict__ gnorm, const double* __restrict__ qlam, const int32_t* __restrict__ rstate, int rbits) {
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B) return;
+    if (rstate && !((rbits >> rstate[r]) & 1)) return;            // route not in a state that needs this sweep (eepacc_nlp_solve)
     __shared__ double M[RY][RY], m[RY], AB[RX][RY], W[RX][RY], P[RX][RX], pv[RX], pc[RX], cvec[RX], Kk[RU][RX + 1], ql[RY], wad[RX];
     const double reg = regg[r];
     const double* Qr = Qg + (size_t)r * N * 100;
@@ -527,10 +528,11 @@ __global__ void __launch_bounds__(64)
 k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ mu_arr, double sigma, const double* __restrict__ s_tv,
              const double* __restrict__ chi, const double* __restrict__ u, const double* __restrict__ lam, const double* __restrict__ tt,
              const double* __restrict__ nu, double* __restrict__ Qo, double* __restrict__ qo, double* __restrict__ ABo,
-             double* __restrict__ co, double* __restrict__ ro, double* __restrict__ qlo) {
+             double* __restrict__ co, double* __restrict__ ro, double* __restrict__ qlo, const int32_t* __restrict__ rstate, int rbits) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)C.N * B) return;
     const int rt = (int)(idx / C.N), k = (int)(idx % C.N);
+    if (rstate && !((rbits >> rstate[rt]) & 1)) return;
     const eepacc_vehicle& V = C.V;
     const double mu = mu_arr[rt];
     const double* x0 = chi + ((size_t)rt * (C.N + 1) + k) * 4;
@@ -691,10 +693,11 @@ k_nlp_newton(const NlpDev C, const double* __restrict__ blob, int B, const doubl
 __global__ void __launch_bounds__(256)
 k_nlp_rowdir(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ s_tv, const double* __restrict__ chi,
              const double* __restrict__ u, const double* __restrict__ dchi, const double* __restrict__ du, double* __restrict__ ro,
-             double* __restrict__ jdy) {
+             double* __restrict__ jdy, const int32_t* __restrict__ rstate, int rbits) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)C.N * B) return;
     const int rt = (int)(idx / C.N), k = (int)(idx % C.N);
+    if (rstate && !((rbits >> rstate[rt]) & 1)) return;
     const double* x1 = chi + ((size_t)rt * (C.N + 1) + k + 1) * 4;
     const double* uk = u + ((size_t)rt * C.N + k) * 6;
     double dy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -725,11 +728,12 @@ k_nlp_rowdir(const NlpDev C, const double* __restrict__ blob, int B, const doubl
 __global__ void __launch_bounds__(64)
 k_nlp_rollout(const NlpDev C, const double* __restrict__ blob, int B, const double* __restrict__ alpha,
               const double* __restrict__ chi0, const double* __restrict__ u0, const double* __restrict__ work,
-              double* __restrict__ chi1, double* __restrict__ u1) {
+              double* __restrict__ chi1, double* __restrict__ u1, const int32_t* __restrict__ rstate, int rbits) {
     // one wavefront per route: the stage's gains, base state and base controls stream global -> registers -> LDS one
     // stage ahead (as in the Riccati sweep); lanes 0..5 form the controls, lane 0 integrates the interval
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B) return;
+    if (rstate && !((rbits >> rstate[r]) & 1)) return;
     const eepacc_vehicle& V = C.V;
     const double ilm = 1.0 / (V.lambda * V.m), mg = V.m * V.g, za = V.zeta_a;
     const Tab t_slope{blob + C.o_slope, blob + C.o_slope + C.n_slope, C.n_slope};
@@ -818,9 +822,10 @@ __device__ __forceinline__ double blk_reduce(double v, double* sh, int op) {    
 __global__ void __launch_bounds__(RED_T)
 k_nlp_steprule(int n, const double* __restrict__ r, const double* __restrict__ t, const double* __restrict__ lam,
                const double* __restrict__ jdy, const double* __restrict__ mu_arr, const double* __restrict__ tau_arr,
-               double* __restrict__ dt, double* __restrict__ dlam, double* __restrict__ out) {
+               double* __restrict__ dt, double* __restrict__ dlam, double* __restrict__ out, const int32_t* __restrict__ rstate, int rbits) {
     __shared__ double sh[RED_T];
     const int rt = blockIdx.x;
+    if (rstate && !((rbits >> rstate[rt]) & 1)) return;
     const size_t base = (size_t)rt * n;
     const double mu = mu_arr[rt], tau = tau_arr[rt];
     double ap = INFINITY, ad = INFINITY, inf_ = 0.0, lami = 0.0, slog = 0.0, eprim = 0.0, c0 = 0.0, cm = 0.0;
@@ -831,6 +836,7 @@ k_nlp_steprule(int n, const double* __restrict__ r, const double* __restrict__ t
         slog += log(tv);
         if (is_i) { inf_ += rg; eprim = fmax(eprim, rg); }
         c0 = fmax(c0, lv * tv);
+        if (!jdy) ap = fmin(ap, lv * tv);                  // without a step: slot 0 carries min lam t (barrier update rule)
         cm = fmax(cm, fabs(lv * tv - mu));
         if (jdy) {
             const double D = lv / tv, jd = jdy[base + e];
@@ -846,7 +852,7 @@ k_nlp_steprule(int n, const double* __restrict__ r, const double* __restrict__ t
     const double v4 = blk_reduce(slog, sh, 0), v5 = blk_reduce(eprim, sh, 2), v6 = blk_reduce(c0, sh, 2), v7 = blk_reduce(cm, sh, 2);
     if (threadIdx.x == 0) {
         double* o = out + (size_t)rt * 8;
-        o[0] = fmin(v0, 1.0); o[1] = fmin(v1, 1.0); o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7;
+        o[0] = jdy ? fmin(v0, 1.0) : v0; o[1] = fmin(v1, 1.0); o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7;
     }
 }
 
@@ -856,9 +862,10 @@ k_nlp_steprule(int n, const double* __restrict__ r, const double* __restrict__ t
 __global__ void __launch_bounds__(RED_T)
 k_nlp_trial(int n, const double* __restrict__ r, const double* __restrict__ t, const double* __restrict__ dt,
             const double* __restrict__ r_t, const double* __restrict__ a_arr, const double* __restrict__ tau_arr,
-            double* __restrict__ t_t, double* __restrict__ out) {
+            double* __restrict__ t_t, double* __restrict__ out, const int32_t* __restrict__ rstate, int rbits) {
     __shared__ double sh[RED_T];
     const int rt = blockIdx.x;
+    if (rstate && !((rbits >> rstate[rt]) & 1)) return;
     const size_t base = (size_t)rt * n;
     const double a = a_arr[rt], tau = tau_arr[rt];
     double bad = 0.0, inf_ = 0.0, slog = 0.0;
@@ -877,12 +884,17 @@ k_nlp_trial(int n, const double* __restrict__ r, const double* __restrict__ t, c
 
 }  // namespace
 
+struct NlpWork;
+static void nlp_work_free(NlpWork* w);
+
 struct eepacc_nlp_handle {
     int device = 0;
     NlpDev C;
     double* d_blob = nullptr;
     double* d_q = nullptr;
     size_t q_cap = 0;
+    std::vector<double> blob_host;      // the lookup tables on the host (start generator of eepacc_run_nlp_host)
+    NlpWork* work = nullptr;            // device workspace of eepacc_nlp_solve (grow-only)
 };
 
 #define NLPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return eepacc::set_error(EEPACC_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -941,6 +953,7 @@ extern "C" int eepacc_nlp_create(eepacc_nlp_handle** out, const eepacc_nlp_probl
     if (p->n_tl) blob.insert(blob.end(), p->tl_s, p->tl_s + 3 * (size_t)p->n_tl);
     C.o_tlstate = (int)blob.size();
     if (p->n_tl) blob.insert(blob.end(), p->tl_state, p->tl_state + (size_t)p->n_tl * p->N);
+    h->blob_host = blob;
     hipError_t e = hipMalloc(&h->d_blob, blob.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -956,6 +969,7 @@ extern "C" void eepacc_nlp_destroy(eepacc_nlp_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_q) (void)hipFree(h->d_q);
+    nlp_work_free(h->work);
     delete h;
 }
 
@@ -1005,7 +1019,7 @@ extern "C" int eepacc_nlp_riccati(int device, int B, int N, const double* Q_dev,
     RicScale sc;
     for (int i = 0; i < 6; ++i) sc.s[i] = reg_scale[i];
     hipLaunchKernelGGL(k_riccati, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, Q_dev, q_dev, AB_dev, c_dev, reg_dev, sc,
-                       dchi_dev, du_dev, nu_dev, work_dev, status_dev, gnorm_dev, qlam_dev);
+                       dchi_dev, du_dev, nu_dev, work_dev, status_dev, gnorm_dev, qlam_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
@@ -1019,7 +1033,7 @@ extern "C" int eepacc_nlp_newton(eepacc_nlp_handle* h, int B, const double* mu_d
     NLPCHK(hipSetDevice(h->device));
     const size_t units = (size_t)h->C.N * B;
     hipLaunchKernelGGL(k_nlp_newton, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, mu_dev, sigma,
-                       s_tv_dev, chi_dev, u_dev, lam_dev, t_dev, nu_dev, Q_dev, q_dev, AB_dev, c_dev, rows_dev, qlam_dev);
+                       s_tv_dev, chi_dev, u_dev, lam_dev, t_dev, nu_dev, Q_dev, q_dev, AB_dev, c_dev, rows_dev, qlam_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
@@ -1030,7 +1044,7 @@ extern "C" int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alp
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_rollout: null argument or B < 1");
     NLPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_nlp_rollout, dim3(B), dim3(64), 0, (hipStream_t)stream, h->C, h->d_blob, B, alpha_dev, chi_dev, u_dev,
-                       work_dev, chi_new_dev, u_new_dev);
+                       work_dev, chi_new_dev, u_new_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
@@ -1042,7 +1056,7 @@ extern "C" int eepacc_nlp_rowdir(eepacc_nlp_handle* h, int B, const double* s_tv
     NLPCHK(hipSetDevice(h->device));
     const size_t units = (size_t)h->C.N * B;
     hipLaunchKernelGGL(k_nlp_rowdir, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->C, h->d_blob, B, s_tv_dev,
-                       chi_dev, u_dev, jdy_dev ? dchi_dev : nullptr, du_dev, rows_dev, jdy_dev);
+                       chi_dev, u_dev, jdy_dev ? dchi_dev : nullptr, du_dev, rows_dev, jdy_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
@@ -1054,7 +1068,7 @@ extern "C" int eepacc_nlp_steprule(int device, int B, int rows_per_route, const 
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_steprule: null argument");
     NLPCHK(hipSetDevice(device));
     hipLaunchKernelGGL(k_nlp_steprule, dim3(B), dim3(RED_T), 0, (hipStream_t)stream, rows_per_route, r_dev, t_dev, lam_dev, jdy_dev, mu_dev,
-                       tau_dev, dt_dev, dlam_dev, out_dev);
+                       tau_dev, dt_dev, dlam_dev, out_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
@@ -1066,7 +1080,9 @@ extern "C" int eepacc_nlp_trial(int device, int B, int rows_per_route, const dou
         return eepacc::set_error(EEPACC_EINVAL, "eepacc_nlp_trial: null argument");
     NLPCHK(hipSetDevice(device));
     hipLaunchKernelGGL(k_nlp_trial, dim3(B), dim3(RED_T), 0, (hipStream_t)stream, rows_per_route, r_dev, t_dev, dt_dev, r_trial_dev, alpha_dev,
-                       tau_dev, t_trial_dev, out_dev);
+                       tau_dev, t_trial_dev, out_dev, nullptr, 0);
     NLPCHK(hipGetLastError());
     return EEPACC_OK;
 }
+
+#include "eepacc_nlp_solve.inc"

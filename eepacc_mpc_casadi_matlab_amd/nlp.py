@@ -201,7 +201,52 @@ def _bind(lib):
     lib.eepacc_nlp_steprule.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 10
     lib.eepacc_nlp_trial.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 9
     lib.eepacc_nlp_riccati.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.eepacc_nlp_solve.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(NlpOptions), vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.eepacc_run_nlp_host.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int32), dp, dp, C.POINTER(NlpOptions),
+                                        dp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, C.POINTER(C.c_int32)]
+    lib.eepacc_nlp_car_following_start_host.argtypes = [vp, dp, C.c_double, C.c_double, C.c_int, C.c_double, dp]
+    lib.eepacc_nlp_problem_from_settings.argtypes = [C.POINTER(vp), C.POINTER(NlpProblemPOD), vp, dp, dp, C.c_double, C.c_double]
+    lib.eepacc_nlp_tables_free.argtypes = [vp]
+    lib.eepacc_nlp_tables_free.restype = None
+    lib.eepacc_nlp_postprocess_host.argtypes = [C.POINTER(Vehicle), dp, dp, C.c_double, C.c_int] + [dp] * 10
     return lib
+
+
+class NlpOptions(C.Structure):
+    """include/eepacc_nlp.h: eepacc_nlp_options (zero / negative entries select the library's defaults)"""
+    _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("max_ls", C.c_int32), ("pad", C.c_int32),
+                ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double), ("obj_scale", C.c_double), ("margin", C.c_double)]
+
+
+DEFAULT_STARTS = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
+
+
+def tables_from_settings(OPTsettings: Dict[str, Any]) -> Dict[str, Any]:
+    """The library's own table preprocessing (eepacc_nlp_problem_from_settings: RunOpt_NLP.m:63-184 in C++, no GPU) as the
+    dict build_tables returns -- what a MEX gateway gets; the CPU tests compare it with an independent restatement."""
+    from .engine import load_library, EepaccError
+    from ._abi import SettingsHolder
+    lib = _bind(load_library())
+    O = dict(OPTsettings)
+    O.setdefault("N_hor", 2); O.setdefault("Tvec", np.full(int(O["N_hor"]), float(O["Ts"])))
+    holder = SettingsHolder(O)
+    p = NlpProblemPOD()
+    owner = C.c_void_p()
+    W = (C.c_double * 7)(*[float(x) for x in np.asarray(OPTsettings["W_NLP"], float)])
+    b = (C.c_double * 21)(*[float(x) for x in np.asarray(OPTsettings["b_fifthOrder"], float)])
+    rc = lib.eepacc_nlp_problem_from_settings(C.byref(owner), C.byref(p), C.byref(holder.pod), W, b, float(OPTsettings["Ts"]), float(OPTsettings["t_sim"]))
+    if rc != 0:
+        raise EepaccError("eepacc_nlp_problem_from_settings failed (%d): %s" % (rc, lib.eepacc_last_error().decode()))
+    try:
+        arr = lambda ptr, n: np.array([ptr[i] for i in range(n)], dtype=np.float64)
+        T = dict(N=int(p.N), flat=bool(p.flat), vlim=(arr(p.s_vlim, p.n_vlim), arr(p.v_vlim, p.n_vlim)),
+                 curv=(arr(p.s_curv, p.n_curv), arr(p.curvature, p.n_curv)), slope=(arr(p.s_slope, p.n_slope), arr(p.slope, p.n_slope)),
+                 stop=(arr(p.s_stop, p.n_stop), arr(p.v_stop, p.n_stop)), vinc=(arr(p.s_vinc, p.n_vinc), arr(p.v_vinc, p.n_vinc)),
+                 tl_v=np.array(list(p.tl_v)), tl_s=arr(p.tl_s, 3 * p.n_tl).reshape(p.n_tl, 3) if p.n_tl else np.zeros((0, 3)),
+                 tl_state=arr(p.tl_state, p.n_tl * p.N).reshape(p.n_tl, p.N) if p.n_tl else np.zeros((0, int(p.N))))
+    finally:
+        lib.eepacc_nlp_tables_free(owner)
+    return T
 
 
 class NlpEvaluator:
@@ -501,6 +546,72 @@ class NlpSolver(NlpEvaluator):
         u[:, :, 5] = torch.maximum(r0[:, :, 0:12].amax(dim=2), zero) + margin
         return chi, u
 
+    def solve_native(self, s_tv, chi0, forces, groups=None, max_iter=1500, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5,
+                     max_ls=4, restarts=3, margin=1.0):
+        """eepacc_nlp_solve (include/eepacc_nlp.h): the whole interior-point iteration on the device -- no tensor operation
+        and no host synchronisation inside an iteration.  s_tv [B][N], chi0 [B][4] = (s_0, v_0, p_0, 0), forces [B][N][2]
+        (Fm, Fb <= 0: the start; states by rollout, slacks `margin` above what the rows need), groups [B] or None (starts of
+        one problem share a group: the first KKT point ends it).  Returns dict(chi, u, J, status, iters, kkt, ticks)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        f64 = torch.float64
+        s_tv = torch.as_tensor(s_tv, dtype=f64, device=dev).contiguous()
+        chi0 = torch.as_tensor(chi0, dtype=f64, device=dev).contiguous()
+        forces = torch.as_tensor(forces, dtype=f64, device=dev).contiguous()
+        B, N = int(forces.shape[0]), self.N
+        assert s_tv.shape == (B, N) and chi0.shape == (B, 4) and forces.shape == (B, N, 2)
+        n_groups = 0
+        if groups is not None:
+            groups = torch.as_tensor(groups, dtype=torch.int32, device=dev).contiguous()
+            n_groups = int(groups.max().item()) + 1
+        chi = torch.empty((B, N + 1, 4), dtype=f64, device=dev)
+        u = torch.empty((B, N, 6), dtype=f64, device=dev)
+        J = torch.empty(B, dtype=f64, device=dev)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        kkt = torch.empty((B, 6), dtype=f64, device=dev)
+        opt = NlpOptions(max_iter=int(max_iter), restarts=int(restarts), max_ls=int(max_ls), tol=float(tol), mu_init=float(mu_init),
+                         mu_min=float(mu_min), obj_scale=float(obj_scale), margin=float(margin))
+        ticks = C.c_int32(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.eepacc_nlp_solve(self.h, B, s_tv.data_ptr(), groups.data_ptr() if groups is not None else None, n_groups,
+                                       chi0.data_ptr(), forces.data_ptr(), C.byref(opt), chi.data_ptr(), u.data_ptr(), J.data_ptr(),
+                                       status.data_ptr(), iters.data_ptr(), kkt.data_ptr(), C.byref(ticks), stream)
+        if rc != 0:
+            raise self._err("eepacc_nlp_solve failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return dict(chi=chi, u=u, J=J, status=status, iters=iters, kkt=kkt, ticks=int(ticks.value))
+
+    def car_following_start_native(self, s_tv, s_init, v_init, lookahead, tau):
+        """eepacc_nlp_car_following_start_host: the library's start generator (what eepacc_run_nlp_host uses); [N][2]."""
+        s_tv = np.ascontiguousarray(s_tv, dtype=np.float64)
+        out = np.zeros((self.N, 2))
+        dp = C.POINTER(C.c_double)
+        rc = self.lib.eepacc_nlp_car_following_start_host(self.h, s_tv.ctypes.data_as(dp), float(s_init), float(v_init), int(lookahead), float(tau),
+                                                          out.ctypes.data_as(dp))
+        if rc != 0:
+            raise self._err("eepacc_nlp_car_following_start_host failed (%d)" % rc)
+        return out
+
+    def run_host(self, s_tv_routes, s_init, v_init, starts=DEFAULT_STARTS, start_forces=None, **opts):
+        """eepacc_run_nlp_host: host arrays in, the optimum of every route out (the entry a MEX gateway calls)."""
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        stv = np.ascontiguousarray(np.asarray(s_tv_routes, dtype=np.float64)[:, :self.N])
+        Rn, N = stv.shape[0], self.N
+        S = 1 if start_forces is not None else len(starts)
+        chi = np.zeros((Rn, N + 1, 4)); u = np.zeros((Rn, N, 6)); J = np.zeros(Rn)
+        status = np.zeros(Rn, dtype=np.int32); iters = np.zeros(Rn, dtype=np.int32); start = np.zeros(Rn, dtype=np.int32)
+        all_J = np.zeros((Rn, S)); all_st = np.zeros((Rn, S), dtype=np.int32)
+        la = np.array([int(L) for (L, _) in starts], dtype=np.int32); tc = np.array([float(t) for (_, t) in starts], dtype=np.float64)
+        sf = np.ascontiguousarray(start_forces, dtype=np.float64) if start_forces is not None else None
+        opt = NlpOptions(**{k: v for k, v in opts.items() if v is not None})
+        rc = self.lib.eepacc_run_nlp_host(self.h, Rn, stv.ctypes.data_as(dp), float(s_init), float(v_init), len(starts), la.ctypes.data_as(ip),
+                                          tc.ctypes.data_as(dp), sf.ctypes.data_as(dp) if sf is not None else None, C.byref(opt),
+                                          chi.ctypes.data_as(dp), u.ctypes.data_as(dp), J.ctypes.data_as(dp), status.ctypes.data_as(ip),
+                                          iters.ctypes.data_as(ip), start.ctypes.data_as(ip), all_J.ctypes.data_as(dp), all_st.ctypes.data_as(ip))
+        if rc != 0:
+            raise self._err("eepacc_run_nlp_host failed (%d): %s" % (rc, self.lib.eepacc_last_error().decode()))
+        return dict(chi=chi, u=u, J=J, status=status, iters=iters, start=start, all_J=all_J, all_status=all_st)
+
     def solve(self, s_tv, chi, u, max_iter=300, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5, max_ls=4,
               reg_first=1e-4, reg_max=1e8, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, verbose=False,
               until_first=False, groups=None, restarts=0, fused=True, accept_tol=1e-13):
@@ -740,13 +851,17 @@ def pick_start(J, status, e_prim, feas_tol: float = 1e-6):
     return torch.where(has1, tier1.argmin(dim=1), torch.where(has2, tier2.argmin(dim=1), viol.argmin(dim=1)))
 
 
-def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts, max_iter: int = 1500,
-                 fused: bool = False, restarts: int = 3):
+def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts=DEFAULT_STARTS, max_iter: int | None = None,
+                 native: bool = True, fused: bool = True, restarts: int = 3):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
-    gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch.  Returns
-    per route: J, status, iterations, index of the winning start, chi [R][N+1][4], u [R][N][6]."""
+    gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch through
+    eepacc_nlp_solve (native = False: the round-2 host loop over the single operators, kept as a cross-check).  max_iter:
+    OPTsettings['NLPmaxIter'] (RunOpt_NLP.m:247) when not given.  Returns per route: J, status, iterations, index of the
+    winning start, chi [R][N+1][4], u [R][N][6]."""
     import torch
     N = sol.N
+    if max_iter is None:
+        max_iter = int(OPTsettings.get("NLPmaxIter", 5000))
     s_tv_routes = np.asarray(s_tv_routes, dtype=np.float64)[:, :N]
     Rn, S = s_tv_routes.shape[0], len(starts)
     s0, v0 = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
@@ -756,60 +871,51 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
     forces = car_following_start(OPTsettings, V, sol.tables, stv, lookahead=np.tile([min(int(L), N - 1) for (L, _) in starts], Rn),
                                  tau=np.tile([float(tc) for (_, tc) in starts], Rn))
     groups = np.repeat(np.arange(Rn), S)
-    chi, u = sol.start_from_controls(stv, np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1)), forces, margin=1.0)
-    # fused = False: on the reference's ABO scenario the one start that reaches the KKT tolerance does so only with the
-    # tensor-operation reductions (the fused kernels sum in another order and that start then ends 8e-6 above)
-    # restarts = 3: with the re-centring restoration a start reaches the saved ABO solution in either arithmetic
-    R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused, restarts=restarts)
+    chi0 = np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1))
+    if native:
+        R = sol.solve_native(stv, chi0, forces, groups=groups, max_iter=max_iter, mu_init=1.0, restarts=restarts, margin=1.0)
+    else:
+        chi, u = sol.start_from_controls(stv, chi0, forces, margin=1.0)
+        R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused, restarts=restarts)
     st = R["status"].view(Rn, S)
     win = pick_start(R["J"].view(Rn, S), st, R["kkt"][:, 1].view(Rn, S))
     idx = torch.arange(Rn, device=win.device) * S + win
     return dict(J=R["J"][idx], status=R["status"][idx], iters=R["iters"][idx], start=win, chi=R["chi"][idx], u=R["u"][idx],
-                all_J=R["J"].view(Rn, S), all_status=st)
+                all_J=R["J"].view(Rn, S), all_status=st, all_kkt=R["kkt"].view(Rn, S, -1), all_iters=R["iters"].view(Rn, S), ticks=R.get("ticks"))
 
 
 def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,
-               max_iter: int = 1500, mu_init: float | None = None,
-               starts=((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))) -> Dict[str, Any]:
-    """`optSol = RunOpt_NLP(OPTsettings)` (ABO/RunOpt_NLP.m, called from ABO/Main.m:124): same fields as the reference's
-    struct.  `OPTsettings["s_tv"]` is the lead trace of Main.m:88.
+               max_iter: int | None = None, mu_init: float | None = None, starts=DEFAULT_STARTS) -> Dict[str, Any]:
+    """`optSol = RunOpt_NLP(OPTsettings)` (ABO/RunOpt_NLP.m, called from ABO/Main.m:97): same fields as the reference's
+    struct, through eepacc_run_nlp_host -- the entry a MEX gateway calls (mex/RunOpt_NLP.c).  `OPTsettings["s_tv"]` is the
+    lead trace of Main.m:88; `OPTsettings["NLPmaxIter"]` the iteration limit of RunOpt_NLP.m:247.
 
     The problem has many local solutions of nearly equal objective (a stop-and-go trajectory behind the lead vehicle is
-    0.5 % above the smooth cruise IPOPT finds from z0 = 0), and the iteration has no restoration phase, so the cold start is
-    a **multi-start in one batch**: car-following rollouts with different look-ahead horizons / response times
-    (`starts` = (look-ahead samples, time constant); chosen from the survey profiles/r02_nlp_start_survey.json) run side by side until the first
-    reaches a KKT point; if none does, the lowest objective is returned with `exitMessage`
-    'Maximum_Iterations_Exceeded' / 'Restoration_Failed' (IPOPT's names for those outcomes).  `start_forces` [N][2]
-    (Fm, Fb) replaces the multi-start by one warm start."""
+    0.5 % above the smooth cruise IPOPT finds from z0 = 0), so the cold start is a **multi-start in one batch**:
+    car-following rollouts with different look-ahead horizons / response times (`starts` = (look-ahead samples, time
+    constant)) run side by side until the first reaches a KKT point; if none does, the best start by
+    eepacc_run_nlp_host's tiers is returned with `exitMessage` 'Maximum_Iterations_Exceeded' / 'Restoration_Failed'
+    (IPOPT's names for those outcomes).  `start_forces` [N][2] (Fm, Fb) replaces the multi-start by one warm start."""
     import time
-    import torch
     from .settings import SetVehicleParameters
     V = V or SetVehicleParameters(OPTsettings.get("tree", "ABO"))
     sol = NlpSolver(OPTsettings, V, device=device)
     N = sol.N
     s_tv = np.asarray(OPTsettings["s_tv"], dtype=np.float64)[:N]
     s0, v0 = float(OPTsettings["s_init"]), float(OPTsettings["v_init"])
-    th0 = 0.0 if sol.tables["flat"] else float(pwa(s0, *sol.tables["slope"])[0])
-    p0 = -(V["zeta_a"] * v0 * v0 + V["c_r"] * V["m"] * V["g"] * math.cos(th0) + V["m"] * V["g"] * math.sin(th0)) / (V["lambda"] * V["m"])
-    warm = start_forces is not None
+    if max_iter is None:
+        max_iter = int(OPTsettings.get("NLPmaxIter", 5000))
     t0 = time.perf_counter()
-    if warm:
-        forces = np.asarray(start_forces, float)[None]
-        chi, u = sol.start_from_controls(s_tv[None], np.array([[s0, v0, p0, 0.0]]), forces, margin=1e-3)
-        R = sol.solve(s_tv[None], chi, u, max_iter=max_iter, mu_init=1e-4 if mu_init is None else mu_init)
-        st, Jb, i = R["status"].cpu().numpy(), R["J"].cpu().numpy(), 0
-        chi, u, n_it = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy(), int(R["iters"][0])
-    else:
-        R = solve_routes(sol, OPTsettings, V, s_tv[None], starts, max_iter=max_iter)
-        st, Jb, i = R["all_status"][0].cpu().numpy(), R["all_J"][0].cpu().numpy(), int(R["start"][0])
-        chi, u, n_it = R["chi"][0].cpu().numpy(), R["u"][0].cpu().numpy(), int(R["iters"][0])
-    sol.synchronize()
+    sf = None if start_forces is None else np.asarray(start_forces, float)[None]
+    R = sol.run_host(s_tv[None], s0, v0, starts=starts, start_forces=sf, max_iter=max_iter, mu_init=mu_init)
     tSolve = time.perf_counter() - t0
+    chi, u, i = R["chi"][0], R["u"][0], int(R["start"][0])
+    st, Jb = R["all_status"][0], R["all_J"][0]
     theta = np.zeros(N + 1) if sol.tables["flat"] else pwa(chi[:, 0], *sol.tables["slope"])[0]
     out = dict(s_velInc=sol.tables["vinc"][0], v_velInc=sol.tables["vinc"][1], tSolve=tSolve,
-               exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(st[i])],
+               exitMessage={0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Restoration_Failed"}[int(R["status"][0])],
                s_opt=chi[:, 0], v_opt=chi[:, 1], theta_opt=theta, j_opt=chi[:, 3], Fm_opt=u[:, 0], Fb_opt=u[:, 1],
                xi_v_opt=u[:, 2], xi_h_opt=u[:, 3], xi_s_opt=u[:, 4], xi_f_opt=u[:, 5],
-               J=float(Jb[i]), iterations=n_it, start_index=i, starts_J=Jb.tolist(), starts_status=st.tolist())
+               J=float(R["J"][0]), iterations=int(R["iters"][0]), start_index=i, starts_J=Jb.tolist(), starts_status=st.tolist())
     out.update(postprocess(OPTsettings, V, chi[:, 1], u[:, 0], chi[:, 3], u[:, 2:]))
     return out

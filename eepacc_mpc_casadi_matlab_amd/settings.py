@@ -252,6 +252,7 @@ def Settings(OPT: Dict[str, Any] | None = None, tree: str = "ABO", N_hor: int = 
     OPT.update(paramEstSetting=1, TVestSetting=1, tConstACC_ego=3.0, tConstACC_tar=5.0)  # :105-108
     OPT["N_integratePlant"] = 10                                             # :111
     OPT["solverToUse"] = 1                                                   # :114
+    OPT["NLPmaxIter"] = 5000                                                 # :93
     OPT["Tvec"] = Ts * np.ones(OPT["N_hor"])                                 # :122
     OPT["s_goal"] = math.inf                                                 # :143
     OPT.update(sRes=1, tRes=1)

@@ -142,7 +142,7 @@ int eepacc_nlp_rollout(eepacc_nlp_handle* h, int B, const double* alpha_dev, con
  * eepacc_nlp_steprule: step dt = -(r + t) - jdy and dlam = (mu/t + (lam/t)(r + t) + (lam/t) jdy) - lam (written if jdy is
  * given) and out [B][8] = fraction-to-the-boundary step lengths a_p, a_d (<= 1), sum of residuals r + t of rows that do
  * not hold (r + t > 1e-9 (1 + t)), largest new multiplier on those rows, sum log t, largest such residual, max lam t,
- * max |lam t - mu|  (the last four alone when jdy is NULL: the convergence measures of the current point).
+ * max |lam t - mu|  (without jdy: slot 0 = min lam t, slots 4..7 = the convergence measures of the current point).
  * eepacc_nlp_trial: slacks of a trial point (rows that hold: t = -r_trial; the others: max(-r_trial, t + alpha dt)) and
  * out [B][3] = all slacks keep the fraction-to-the-boundary distance (1 / 0), sum of residuals of rows that do not
  * hold, sum log t_trial. */
@@ -152,6 +152,76 @@ int eepacc_nlp_steprule(int device, int B, int rows_per_route, const double* r_d
 int eepacc_nlp_trial(int device, int B, int rows_per_route, const double* r_dev, const double* t_dev, const double* dt_dev,
                      const double* r_trial_dev, const double* alpha_dev, const double* tau_dev, double* t_trial_dev,
                      double* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The solver: `sol = solver('x0',z0,'lbx',...,'ubg',...)` of ABO/RunOpt_NLP.m:505-510 (IPOPT with the options of :246-252)
+ * for a batch of routes, entirely on the device.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* Options; zero / negative entries select the defaults in brackets. */
+typedef struct eepacc_nlp_options {
+    int32_t max_iter;        /* OPTsettings.NLPmaxIter (RunOpt_NLP.m:247)                                      [1500] */
+    int32_t restarts;        /* re-centrings of a route whose line search fails at every Levenberg term; < 0:   [3]    */
+    int32_t max_ls;          /* step halvings per factorisation                                                [4]    */
+    int32_t pad;
+    double  tol;             /* KKT tolerance: dual residual, constraint violation, complementarity            [1e-7] */
+    double  mu_init;         /* first barrier parameter                                                        [1.0]  */
+    double  mu_min;          /* its floor                                                                      [1e-9] */
+    double  obj_scale;       /* objective scaling of the iteration (the reported objective is unscaled)        [1e-5] */
+    double  margin;          /* slack margin of the start point                                                [1.0]  */
+} eepacc_nlp_options;
+
+/* Interior-point solve of B problem instances.  Every instance is one route with one start; the
+ * iteration (Newton system: eepacc_nlp_newton, factorisation: eepacc_nlp_riccati, closed-loop rollout: eepacc_nlp_rollout,
+ * rows / step rules / merit) and all its per-route decisions -- barrier parameter, Levenberg term, fraction-to-the-boundary
+ * step lengths, l1 merit, accept / reject, re-centring restoration, termination -- run on the device; the host only
+ * launches and reads one counter every few rounds.
+ *   s_tv_dev   [B][N]     lead-vehicle position per instance (route-major)
+ *   group_dev  [B] / NULL instances of one group are starts of the same problem: the first that reaches a KKT point ends
+ *                         its group (ids 0 .. n_groups-1)
+ *   chi0_dev   [B][4]     node 0: (s_init, v_init, p_0, 0), p_0 = acceleration under zero force (RunOpt_NLP.m:337,371-375)
+ *   forces_dev [B][N][2]  start: (Fm, Fb <= 0) per interval; states by rollout, slacks `margin` above what the rows need
+ * Outputs: chi_dev [B][N+1][4] (s, v, p, j per node), u_dev [B][N][6] (Fm, Fb, xi_v, xi_h, xi_s, xi_f), J_dev [B]
+ * (objective), status_dev [B] (0 KKT point to `tol` = IPOPT's Solve_Succeeded, 1 iteration limit, 2 no acceptable step at
+ * any Levenberg term after the restoration attempts), iters_dev [B] / NULL, kkt_dev [B][6] / NULL (dual residual,
+ * constraint violation, complementarity at the last convergence test; barrier parameter, Levenberg term, restorations used), *ticks_out / NULL (rounds of launches). */
+int eepacc_nlp_solve(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const int32_t* group_dev, int n_groups,
+                     const double* chi0_dev, const double* forces_dev, const eepacc_nlp_options* options,
+                     double* chi_dev, double* u_dev, double* J_dev, int32_t* status_dev, int32_t* iters_dev,
+                     double* kkt_dev, int32_t* ticks_out, void* stream);
+
+/* B1 -- `NLPsol = RunOpt_NLP(OPTsettings)` (ABO/Main.m:97, ABO/RunOpt_NLP.m:1) for n_routes routes that share the handle's
+ * route tables and differ in their lead trace s_tv_host [n_routes][N] (sample k = s_tv(k+1), :488-499).  Host pointers in
+ * and out (what a MEX gateway holds).  The reference starts IPOPT from z0 = 0 (:348); here every route gets n_starts
+ * car-following force trajectories (look-ahead samples / response time per start: eepacc_nlp_car_following_start_host)
+ * solved side by side as one group, or -- start_forces_host [n_routes][N][2] given -- one warm start.
+ * Outputs per route: chi_host [n_routes][N+1][4], u_host [n_routes][N][6], J_host, status_host (as eepacc_nlp_solve),
+ * iters_host / NULL, start_host / NULL (index of the winning start), all_J_host / all_status_host [n_routes][n_starts] / NULL.
+ * Winner: lowest objective among the starts at a KKT point; if none, among the primal-feasible ones; else the smallest
+ * constraint violation. */
+int eepacc_run_nlp_host(eepacc_nlp_handle* h, int n_routes, const double* s_tv_host, double s_init, double v_init, int n_starts,
+                        const int32_t* start_lookahead, const double* start_tau, const double* start_forces_host,
+                        const eepacc_nlp_options* options, double* chi_host, double* u_host, double* J_host,
+                        int32_t* status_host, int32_t* iters_host, int32_t* start_host, double* all_J_host,
+                        int32_t* all_status_host);
+int eepacc_nlp_car_following_start_host(eepacc_nlp_handle* h, const double* s_tv_host, double s_init, double v_init, int lookahead,
+                                        double tau, double* forces_host /* [N][2] */);
+
+/* Host-side problem construction of RunOpt_NLP.m:63-184 from the route description of eepacc_settings (speed limits,
+ * curvature, slope, stops, traffic lights and their constants): stop and traffic-light profiles and the velocity-incentive
+ * profile through minPWA / SaturateSlopePWA / FixCrossingPWA / SimplifyPWA (ABO/Functions/PWA_function_manipulation/).
+ * Fills *p (tables point into *owner, free it with eepacc_nlp_tables_free after eepacc_nlp_create).  No GPU needed.
+ * W_NLP [7] (Settings.m:12-29), b [21] (b_fifthOrder, or b_quadr followed by 15 zeros). */
+typedef struct eepacc_nlp_tables eepacc_nlp_tables;
+int  eepacc_nlp_problem_from_settings(eepacc_nlp_tables** owner, eepacc_nlp_problem* p, const eepacc_settings* S,
+                                      const double W_NLP[7], const double b[21], double Ts, double t_sim);
+void eepacc_nlp_tables_free(eepacc_nlp_tables* t);
+
+/* Derived quantities of optSol (RunOpt_NLP.m:545-605) on the host: rpm, P (fifth-order surface), E, a, Tm [N] and, if
+ * cost is given, the seven running cost series [7][N] (P, a, j, xi_v, xi_h, xi_s, xi_f). */
+int eepacc_nlp_postprocess_host(const eepacc_vehicle* V, const double b_fifthOrder[21], const double W_NLP[7], double Ts, int N,
+                                const double* v_opt, const double* Fm_opt, const double* j_opt, const double* slacks,
+                                double* rpm, double* P, double* E, double* a, double* Tm, double* cost);
 
 #ifdef __cplusplus
 }

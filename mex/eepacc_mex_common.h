@@ -99,6 +99,7 @@ static void emx_vehicle(eepacc_vehicle* V) {
     mxDestroyArray(out);
 }
 
+#ifndef EEPACC_MEX_NO_CLOSED_LOOP     /* RunOpt_NLP.c shares the field readers above, not the closed-loop struct builders */
 /* read every OPTsettings field of the path into the PODs of include/eepacc.h.  fb: FBMPC (W_FB) or ABMPC (W_AB) */
 static void emx_read_inputs(const mxArray* O, int fb, eepacc_mex_inputs* in) {
     int n, n2;
@@ -191,12 +192,15 @@ static double emx_power(double x, double y, const double* b) {
            b[18] * x2 * y3 + b[19] * x * y4 + b[20] * y5;
 }
 
+#endif /* EEPACC_MEX_NO_CLOSED_LOOP */
+
 static mxArray* emx_col(int n) { return mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); }
 static void emx_set(mxArray* S, const char* name, mxArray* v) {
     if (mxGetFieldNumber(S, name) < 0) mxAddField(S, name);
     mxSetField(S, 0, name, v);
 }
 
+#ifndef EEPACC_MEX_NO_CLOSED_LOOP
 /* Build optSol from the trajectory block traj[n][EEPACC_OUT_N] and status[n] (B = 1).
  * cost_names / cost_w / cost_src: the cumulative cost series of the controller (RunOpt_ABMPC.m:383-404,
  * RunOpt_FBMPC.m:373-397); src 0..6 = P^2, a^2, j^2, xi_v, xi_h, xi_s, xi_f. */
@@ -266,5 +270,6 @@ static mxArray* emx_build_optsol(const eepacc_mex_inputs* in, const double* traj
     }
     return sol;
 }
+#endif /* EEPACC_MEX_NO_CLOSED_LOOP */
 
 #endif /* EEPACC_MEX_COMMON_H */

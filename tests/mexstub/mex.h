@@ -24,6 +24,8 @@ bool mxIsLogical(const mxArray* pm);
 bool mxIsComplex(const mxArray* pm);
 bool mxIsEmpty(const mxArray* pm);
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
+mxArray* mxCreateDoubleScalar(double value);
+mxArray* mxCreateString(const char* str);
 mxArray* mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char** fieldnames);
 int mxAddField(mxArray* pm, const char* fieldname);
 int mxGetFieldNumber(const mxArray* pm, const char* fieldname);

@@ -90,12 +90,15 @@ def test_nlp_header_symbols_and_layout(lib):
     ctypes mirror of eepacc_nlp_problem has the compiled size, and creation fails loudly without a GPU."""
     from eepacc_mpc_casadi_matlab_amd import nlp
     hdr = open(os.path.join(ROOT, "include", "eepacc_nlp.h")).read()
-    declared = sorted(set(re.findall(r"\b(eepacc_nlp_[a-z_0-9]+)\s*\(", hdr)))
-    assert declared == ["eepacc_nlp_create", "eepacc_nlp_destroy", "eepacc_nlp_eval", "eepacc_nlp_newton", "eepacc_nlp_riccati", "eepacc_nlp_rollout", "eepacc_nlp_rowdir", "eepacc_nlp_rows",
-                        "eepacc_nlp_sizeof_problem", "eepacc_nlp_steprule", "eepacc_nlp_synchronize", "eepacc_nlp_trial"]
+    declared = sorted(set(re.findall(r"\b(eepacc_(?:run_)?nlp_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == ["eepacc_nlp_car_following_start_host", "eepacc_nlp_create", "eepacc_nlp_destroy", "eepacc_nlp_eval", "eepacc_nlp_newton",
+                        "eepacc_nlp_postprocess_host", "eepacc_nlp_problem_from_settings", "eepacc_nlp_riccati", "eepacc_nlp_rollout",
+                        "eepacc_nlp_rowdir", "eepacc_nlp_rows", "eepacc_nlp_sizeof_problem", "eepacc_nlp_solve", "eepacc_nlp_steprule",
+                        "eepacc_nlp_synchronize", "eepacc_nlp_tables_free", "eepacc_nlp_trial", "eepacc_run_nlp_host"]
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.eepacc_nlp_sizeof_problem() == C.sizeof(nlp.NlpProblemPOD)
+    assert C.sizeof(nlp.NlpOptions) == 4 * 4 + 5 * 8                     # eepacc_nlp_options: four int32, five doubles
     if _no_gpu():
         OPT, V, s_tv, v_tv = make_case("ABO", 20)
         with pytest.raises(engine.EepaccError, match="no HIP device"):

@@ -14,6 +14,66 @@ from conftest import ROOT
 MEX = os.path.join(ROOT, "mex")
 
 
+def test_nlp_gateway_compiles_binds_and_covers_the_reference_fields(tmp_path):
+    """mex/RunOpt_NLP.c (`NLPsol = RunOpt_NLP(OPTsettings)`, ABO/Main.m:97): warning-free C against the MEX API, bound to the
+    host entry points of include/eepacc_nlp.h, reading the OPTsettings fields of RunOpt_NLP.m:17-49 (+ NLPmaxIter, :248) and
+    writing every optSol field of :181-182, 509-510, 545-605."""
+    src = os.path.join(MEX, "RunOpt_NLP.c")
+    obj = tmp_path / "RunOpt_NLP.o"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-c", src, "-o", str(obj),
+           "-I", os.path.join(ROOT, "tests", "mexstub"), "-I", os.path.join(ROOT, "include")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True).stdout
+    for need in ("eepacc_nlp_problem_from_settings", "eepacc_nlp_create", "eepacc_run_nlp_host", "eepacc_nlp_postprocess_host",
+                 "eepacc_nlp_destroy", "eepacc_nlp_tables_free", "eepacc_last_error", "mexCallMATLAB", "mexErrMsgIdAndTxt"):
+        assert re.search(r"\b%s\b" % need, syms), need
+    assert "mexFunction" in subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout
+    text = open(src).read()
+    read = set(re.findall(r'emx_(?:scalar|scalar_opt|vector)\(O, "(\w+)"', text)) | set(re.findall(r'mxGetField\(O, 0, "(\w+)"\)', text))
+    need = {"W_NLP", "b_quadr", "b_fifthOrder", "useFifthOrderFit_NLP", "shootingMethod", "discretizationMethod", "Tvec", "t_sim",
+            "s_init", "v_init", "s_goal", "s_speedLim", "v_speedLim", "s_curv", "curvature", "s_slope", "slope", "stopLoc",
+            "stopRefDist", "stopRefVelSlope", "stopVel", "TLLoc", "TLstopVel", "alpha_TTL", "s_tv", "h_min", "tau_min", "NLPmaxIter"}
+    assert need <= read, need - read
+    written = set(re.findall(r'emx_set\(sol, "(\w+)"', text)) | set(re.findall(r'"(\w+_opt|cost_\w+)"', text))
+    out = {"s_velInc", "v_velInc", "tSolve", "exitMessage", "s_opt", "v_opt", "theta_opt", "j_opt", "Fm_opt", "Fb_opt", "xi_v_opt",
+           "xi_h_opt", "xi_s_opt", "xi_f_opt", "P_opt", "E_opt", "a_opt", "Tm_opt", "rpm_opt", "cost_P", "cost_a", "cost_j",
+           "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f"}
+    assert out <= written, out - written
+    for msg in ("Solve_Succeeded", "Maximum_Iterations_Exceeded", "Restoration_Failed"):      # IPOPT's return_status names
+        assert msg in text
+
+
+def test_nlp_postprocess_host_equals_the_python_mirror():
+    """eepacc_nlp_postprocess_host (what the gateway fills optSol's derived fields with; no GPU) on the saved IPOPT solution:
+    the fields of RunOpt_NLP.m:545-605 as saved by the reference."""
+    import ctypes as C
+    import numpy as np
+    from conftest import load_golden, make_case
+    from eepacc_mpc_casadi_matlab_amd import engine
+    from eepacc_mpc_casadi_matlab_amd._abi import make_vehicle
+    from eepacc_mpc_casadi_matlab_amd.nlp import _bind
+    lib = _bind(engine.load_library())
+    OPT, V, _, _ = make_case("ABO")
+    G = load_golden("abo_nlp")
+    N = 870
+    dp = C.POINTER(C.c_double)
+    arr = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    v, Fm, j = arr(G["v_opt"]), arr(G["Fm_opt"]), arr(G["j_opt"])
+    sl = arr(np.stack([G["xi_v_opt"], G["xi_h_opt"], G["xi_s_opt"], G["xi_f_opt"]], axis=1))
+    outs = [np.zeros(N) for _ in range(5)]
+    cost = np.zeros((7, N))
+    b = (C.c_double * 21)(*[float(x) for x in OPT["b_fifthOrder"]]); W = (C.c_double * 7)(*[float(x) for x in OPT["W_NLP"]])
+    veh = make_vehicle(V)
+    rc = lib.eepacc_nlp_postprocess_host(C.byref(veh), b, W, 0.5, N, v.ctypes.data_as(dp), Fm.ctypes.data_as(dp), j.ctypes.data_as(dp),
+                                         sl.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in outs], cost.ctypes.data_as(dp))
+    assert rc == 0
+    for o, key in zip(outs, ("rpm_opt", "P_opt", "E_opt", "a_opt", "Tm_opt")):
+        np.testing.assert_allclose(o, G[key], rtol=1e-11, atol=1e-9, err_msg=key)
+    for i, key in enumerate(("cost_P", "cost_a", "cost_j", "cost_xi_v", "cost_xi_h", "cost_xi_s", "cost_xi_f")):
+        np.testing.assert_allclose(cost[i], G[key], rtol=1e-10, atol=1e-6, err_msg=key)
+
+
 @pytest.mark.parametrize("src", ["RunOpt_ABMPC.c", "RunOpt_FBMPC.c", "RunOpt_BLMPC.c"])
 def test_gateway_compiles_against_the_mex_api(src, tmp_path):
     obj = tmp_path / (src + ".o")

@@ -106,6 +106,32 @@ def test_product_table_preprocessing_equals_the_oracles_restatement():
     assert n_knots > 40                                            # the incentive tables are not trivial
 
 
+def test_library_table_preprocessing_equals_the_oracles_restatement():
+    """eepacc_nlp_problem_from_settings (the C++ problem construction a MEX gateway for RunOpt_NLP calls; no GPU) against
+    the oracle's restatement on the same feature routes, and on both saved solutions' own tables."""
+    from eepacc_mpc_casadi_matlab_amd.nlp import tables_from_settings
+    from oracle import nlp_tables as checker
+    cases = list(_feature_routes())
+    for tree in ("ABO", "ORIG"):
+        OPT, _, _, _ = make_case(tree=tree)
+        cases.append((tree, OPT))
+    for name, OPT in cases:
+        Tl, Tc = tables_from_settings(OPT), checker.build_tables(OPT)
+        assert Tl["N"] == Tc["N"] and Tl["flat"] == Tc["flat"], name
+        for key in ("vlim", "curv", "stop", "vinc"):
+            for a, b in zip(Tl[key], Tc[key]):
+                assert a.shape == b.shape, (name, key, a.shape, b.shape)
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg="%s %s" % (name, key))
+        for key in ("tl_s", "tl_v", "tl_state"):
+            np.testing.assert_array_equal(Tl[key], Tc[key], err_msg="%s %s" % (name, key))
+        x = np.linspace(-10.0, 4000.0, 801)
+        np.testing.assert_allclose(checker.lookup(x, *Tl["slope"])[0], checker.lookup(x, *Tc["slope"])[0], rtol=0, atol=1e-15)
+    G = load_golden("abo_nlp")
+    Tl = tables_from_settings(make_case(tree="ABO")[0])
+    np.testing.assert_allclose(Tl["vinc"][0], G["s_velInc"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Tl["vinc"][1], G["v_velInc"], rtol=0, atol=1e-12)
+
+
 def test_oracle_does_not_import_the_products_solver_or_tables():
     """oracle/ may use the product's ABI mirror (struct layouts) but none of its algorithms."""
     import os, re
