@@ -37,6 +37,24 @@ __device__ __forceinline__ void pwa(const Tab t, double x, double& val, double& 
     val = t.y[i] + slope * (x - t.x[i]);
 }
 
+// Lookup in a table stored as a piecewise QUADRATIC: on segment i (width dx, chord slope m) the value is
+// y_i + m d + c_i d (d - dx), d = x - x_i; c_i = 0 gives the piecewise-linear table of casadi.interpolant('LUT','linear').
+// The solver's copy of the position tables has every kink rounded this way over +- eps (two extra knots per interior
+// knot, a parabola between them that matches both neighbours in value and slope: C^1), because the minimiser of a route
+// can sit exactly on a knot -- a node at the end of the 1 m speed-limit ramp -- where the piecewise-linear problem has no
+// KKT point in the classical sense and a Newton-type iteration stalls.
+struct TabQ { const double* x; const double* y; const double* c; int n; };
+__device__ __forceinline__ void pwq(const TabQ t, double x, double& val, double& slope, double& curv) {
+    int i = 0;
+    for (int q = 1; q < t.n - 1; ++q) i = (t.x[q] <= x) ? q : i;
+    const double dx = t.x[i + 1] - t.x[i], d = x - t.x[i], c = t.c[i];
+    const double m = dx > 0.0 ? (t.y[i + 1] - t.y[i]) / dx : 0.0;
+    slope = fma(c, 2.0 * d - dx, m);
+    val = fma(d, fma(c, d - dx, m), t.y[i]);
+    curv = 2.0 * c;
+}
+__device__ __forceinline__ TabQ tabq(const double* blob, int off, int n) { return TabQ{blob + off, blob + off + n, blob + off + 2 * n, n}; }
+
 // The speed along the interval depends on (v_k, theta_k, F_k) only; the motor force Fm_k enters the running cost
 // alone.  So the sensitivities are carried as 3-direction jets (value + d/dv_k, d/dtheta_k, d/dF_k) and the power
 // polynomial contributes through its two scalar partials.
@@ -441,29 +459,31 @@ __device__ __forceinline__ void nlp_rows(const NlpDev& C, const double* __restri
     { const int ix[5] = {4, 2, 1, 0, 9}; const double g[5] = {kF, -V.h_g * V.lambda, -2.0 * kz * vN, -drear, -1.0}; const int n_last = row(kF * Fm - rear - xf, 5, ix, g); curv(n_last, 1, 1, -2.0 * kz); }
     const double iso_v[4] = {0.0, 5.0, 20.0, 25.0};
     const double iso_amin[4] = {-4.0, -4.0, -2.0, -2.0}, iso_amax[4] = {5.0, 5.0, 3.5, 3.5}, iso_j[4] = {5.0, 5.0, 2.5, 2.5};
+    double cv = 0.0;                                       // curvature of a rounded kink (pwq); the ISO speed tables stay exact
     pwa(Tab{iso_v, iso_amin, 4}, vN, val, sl);
-    { const int ix[3] = {2, 1, 9}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(pN - val + xf), 3, ix, g); }
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(pN - val + xf), 3, ix, g); if (cv != 0.0) curv(n_last, 1, 1, cv); }
     pwa(Tab{iso_v, iso_amax, 4}, vN, val, sl);
-    { const int ix[3] = {2, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(pN - val - xf, 3, ix, g); }
+    { const int ix[3] = {2, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(pN - val - xf, 3, ix, g); if (cv != 0.0) curv(n_last, 1, 1, -cv); }
     pwa(Tab{iso_v, iso_j, 4}, vN, val, sl);
-    { const int ix[3] = {3, 1, 9}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(jN + val + xf), 3, ix, g); }
-    { const int ix[3] = {3, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(jN - val - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_vlim, blob + C.o_vlim + C.n_vlim, C.n_vlim}, sN, val, sl);
-    { const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_curv, blob + C.o_curv + C.n_curv, C.n_curv}, sN, val, sl);
-    { const double ac = fmax(fabs(val), 1e-300);
-      const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * (val > 0 ? 1.0 : (val < 0 ? -1.0 : 0.0)) * sl, -1.0};
-      (void)row(vN - C.alpha * pow(ac, -1.0 / 3.0) - xf, 3, ix, g); }
-    pwa(Tab{blob + C.o_stop, blob + C.o_stop + C.n_stop, C.n_stop}, sN, val, sl);
-    { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xs, 3, ix, g); }
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(jN + val + xf), 3, ix, g); if (cv != 0.0) curv(n_last, 1, 1, -cv); }
+    { const int ix[3] = {3, 1, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(jN - val - xf, 3, ix, g); if (cv != 0.0) curv(n_last, 1, 1, -cv); }
+    pwq(tabq(blob, C.o_vlim, C.n_vlim), sN, val, sl, cv);
+    { const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xf, 3, ix, g); if (cv != 0.0) curv(n_last, 0, 0, -cv); }
+    pwq(tabq(blob, C.o_curv, C.n_curv), sN, val, sl, cv);
+    { const double ac = fmax(fabs(val), 1e-300), sg = (val > 0 ? 1.0 : (val < 0 ? -1.0 : 0.0));
+      const int ix[3] = {1, 0, 9}; const double g[3] = {1.0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * sg * sl, -1.0};
+      const int n_last = row(vN - C.alpha * pow(ac, -1.0 / 3.0) - xf, 3, ix, g);
+      if (cv != 0.0) curv(n_last, 0, 0, C.alpha / 3.0 * pow(ac, -4.0 / 3.0) * sg * cv); }
+    pwq(tabq(blob, C.o_stop, C.n_stop), sN, val, sl, cv);
+    { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - xs, 3, ix, g); if (cv != 0.0) curv(n_last, 0, 0, -cv); }
     for (int tl = 0; tl < C.n_tl; ++tl) {
-        pwa(Tab{blob + C.o_tls + 3 * tl, C.tl_v, 3}, sN, val, sl);
+        pwa(Tab{blob + C.o_tls + 3 * tl, C.tl_v, 3}, sN, val, sl); cv = 0.0;       // traffic-light profiles stay exact
         const double tst = blob[C.o_tlstate + (size_t)tl * C.N + k];
-        { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - tst - xs, 3, ix, g); }
-        { const int ix[3] = {1, 0, 8}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(vN + val + 1e3 - 10.0 - tst + xs), 3, ix, g); }
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {1.0, -sl, -1.0}; const int n_last = row(vN - val - tst - xs, 3, ix, g); if (cv != 0.0) curv(n_last, 0, 0, -cv); }
+        { const int ix[3] = {1, 0, 8}; const double g[3] = {-1.0, -sl, -1.0}; const int n_last = row(-(vN + val + 1e3 - 10.0 - tst + xs), 3, ix, g); if (cv != 0.0) curv(n_last, 0, 0, -cv); }
     }
-    pwa(Tab{blob + C.o_vinc, blob + C.o_vinc + C.n_vinc, C.n_vinc}, sN, val, sl);
-    { const int ix[3] = {1, 0, 6}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(vN - val + xv), 3, ix, g); }
+    pwq(tabq(blob, C.o_vinc, C.n_vinc), sN, val, sl, cv);
+    { const int ix[3] = {1, 0, 6}; const double g[3] = {-1.0, sl, -1.0}; const int n_last = row(-(vN - val + xv), 3, ix, g); if (cv != 0.0) curv(n_last, 0, 0, cv); }
     { const int ix[1] = {0}; const double g[1] = {1.0}; const int n_last = row(sN - (stv - C.h_min), 1, ix, g); }
     { const int ix[3] = {0, 1, 8}; const double g[3] = {1.0, C.tau_min, -1.0}; const int n_last = row(sN + C.tau_min * vN - xs - stv, 3, ix, g); }
     const double T_hwp = 2.0, A_hwp = 2.0, G_hwp = -0.0246 * T_hwp + 0.010819;
@@ -894,8 +914,52 @@ struct eepacc_nlp_handle {
     double* d_q = nullptr;
     size_t q_cap = 0;
     std::vector<double> blob_host;      // the lookup tables on the host (start generator of eepacc_run_nlp_host)
+    NlpDev Cr;                          // the solver's copy: position tables with their kinks rounded over +- eps_r
+    double* d_blob_r = nullptr;
+    double eps_r = 0.0;
+    std::vector<double> tabs_host[5][2];   // the five tables as given (knots, values): source of the rounded copies
+    std::vector<double> tl_s_host, tl_state_host;
     NlpWork* work = nullptr;            // device workspace of eepacc_nlp_solve (grow-only)
 };
+
+// Table blob of a handle: per table [knots | values | c] (pwq), then the traffic-light knots and phases.  eps > 0 rounds
+// every interior kink of the four position tables (speed limit, curvature, stop profile, velocity incentive): knot j is
+// replaced by the two knots x_j -+ e_j, e_j = min(eps, half the shorter adjoining segment), with the parabola coefficient
+// (slope_right - slope_left) / (4 e_j) on the segment between them.  The slope table and eps = 0 stay exact (c = 0).
+static void nlp_build_blob(const eepacc_nlp_handle* h, double eps, NlpDev& C, std::vector<double>& blob) {
+    blob.clear();
+    auto push = [&](int which, bool round, int& n_out) {
+        const std::vector<double>& x = h->tabs_host[which][0];
+        const std::vector<double>& y = h->tabs_host[which][1];
+        const int n = (int)x.size();
+        std::vector<double> X, Y, Cq;
+        auto add = [&](double xv, double yv, double cv) { X.push_back(xv); Y.push_back(yv); Cq.push_back(cv); };
+        add(x[0], y[0], 0.0);
+        for (int j = 1; j + 1 < n; ++j) {
+            const double gl = x[j] - x[j - 1], gr = x[j + 1] - x[j];
+            if (!round || !(eps > 0.0) || !(gl > 0.0) || !(gr > 0.0)) { add(x[j], y[j], 0.0); continue; }     // a jump stays a jump
+            const double sL = (y[j] - y[j - 1]) / gl, sR = (y[j + 1] - y[j]) / gr;
+            if (sL == sR) { add(x[j], y[j], 0.0); continue; }
+            const double e = std::fmin(eps, 0.5 * std::fmin(gl, gr));
+            add(x[j] - e, y[j] - sL * e, (sR - sL) / (4.0 * e));
+            add(x[j] + e, y[j] + sR * e, 0.0);
+        }
+        add(x[n - 1], y[n - 1], 0.0);
+        const int o = (int)blob.size();
+        blob.insert(blob.end(), X.begin(), X.end()); blob.insert(blob.end(), Y.begin(), Y.end()); blob.insert(blob.end(), Cq.begin(), Cq.end());
+        n_out = (int)X.size();
+        return o;
+    };
+    C.o_vlim = push(0, true, C.n_vlim);
+    C.o_curv = push(1, true, C.n_curv);
+    C.o_slope = push(2, false, C.n_slope);
+    C.o_stop = push(3, true, C.n_stop);
+    C.o_vinc = push(4, true, C.n_vinc);
+    C.o_tls = (int)blob.size();
+    blob.insert(blob.end(), h->tl_s_host.begin(), h->tl_s_host.end());
+    C.o_tlstate = (int)blob.size();
+    blob.insert(blob.end(), h->tl_state_host.begin(), h->tl_state_host.end());
+}
 
 #define NLPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return eepacc::set_error(EEPACC_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -942,17 +1006,10 @@ extern "C" int eepacc_nlp_create(eepacc_nlp_handle** out, const eepacc_nlp_probl
     C.Fm_min = -V->phi * V->T_m_max / V->eta_TF;                                           // RunOpt_NLP.m:194-195
     C.Fm_max = V->phi * V->T_m_max * V->eta_TF;
     std::memcpy(C.tl_v, p->tl_v, sizeof(C.tl_v));
+    for (int i = 0; i < 5; ++i) { h->tabs_host[i][0].assign(tabs[i].x, tabs[i].x + tabs[i].n); h->tabs_host[i][1].assign(tabs[i].y, tabs[i].y + tabs[i].n); }
+    if (p->n_tl) { h->tl_s_host.assign(p->tl_s, p->tl_s + 3 * (size_t)p->n_tl); h->tl_state_host.assign(p->tl_state, p->tl_state + (size_t)p->n_tl * p->N); }
     std::vector<double> blob;
-    auto push = [&](const T& t) { int o = (int)blob.size(); blob.insert(blob.end(), t.x, t.x + t.n); blob.insert(blob.end(), t.y, t.y + t.n); return o; };
-    C.n_vlim = p->n_vlim; C.o_vlim = push(tabs[0]);
-    C.n_curv = p->n_curv; C.o_curv = push(tabs[1]);
-    C.n_slope = p->n_slope; C.o_slope = push(tabs[2]);
-    C.n_stop = p->n_stop; C.o_stop = push(tabs[3]);
-    C.n_vinc = p->n_vinc; C.o_vinc = push(tabs[4]);
-    C.o_tls = (int)blob.size();
-    if (p->n_tl) blob.insert(blob.end(), p->tl_s, p->tl_s + 3 * (size_t)p->n_tl);
-    C.o_tlstate = (int)blob.size();
-    if (p->n_tl) blob.insert(blob.end(), p->tl_state, p->tl_state + (size_t)p->n_tl * p->N);
+    nlp_build_blob(h, 0.0, C, blob);                    // the exact tables: function evaluator and the single operators
     h->blob_host = blob;
     hipError_t e = hipMalloc(&h->d_blob, blob.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -969,6 +1026,7 @@ extern "C" void eepacc_nlp_destroy(eepacc_nlp_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_q) (void)hipFree(h->d_q);
+    if (h->d_blob_r) (void)hipFree(h->d_blob_r);
     nlp_work_free(h->work);
     delete h;
 }

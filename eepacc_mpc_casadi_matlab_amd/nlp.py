@@ -215,7 +215,8 @@ def _bind(lib):
 class NlpOptions(C.Structure):
     """include/eepacc_nlp.h: eepacc_nlp_options (zero / negative entries select the library's defaults)"""
     _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("max_ls", C.c_int32), ("pad", C.c_int32),
-                ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double), ("obj_scale", C.c_double), ("margin", C.c_double)]
+                ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double), ("obj_scale", C.c_double), ("margin", C.c_double),
+                ("kink_eps_s", C.c_double), ("kink_eps_v", C.c_double)]
 
 
 DEFAULT_STARTS = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
@@ -547,7 +548,7 @@ class NlpSolver(NlpEvaluator):
         return chi, u
 
     def solve_native(self, s_tv, chi0, forces, groups=None, max_iter=1500, mu_init=1.0, mu_min=1e-9, tol=1e-7, obj_scale=1e-5,
-                     max_ls=4, restarts=3, margin=1.0):
+                     max_ls=4, restarts=3, margin=1.0, kink_eps_s=0.0, kink_eps_v=0.0):
         """eepacc_nlp_solve (include/eepacc_nlp.h): the whole interior-point iteration on the device -- no tensor operation
         and no host synchronisation inside an iteration.  s_tv [B][N], chi0 [B][4] = (s_0, v_0, p_0, 0), forces [B][N][2]
         (Fm, Fb <= 0: the start; states by rollout, slacks `margin` above what the rows need), groups [B] or None (starts of
@@ -571,7 +572,8 @@ class NlpSolver(NlpEvaluator):
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         kkt = torch.empty((B, 6), dtype=f64, device=dev)
         opt = NlpOptions(max_iter=int(max_iter), restarts=int(restarts), max_ls=int(max_ls), tol=float(tol), mu_init=float(mu_init),
-                         mu_min=float(mu_min), obj_scale=float(obj_scale), margin=float(margin))
+                         mu_min=float(mu_min), obj_scale=float(obj_scale), margin=float(margin), kink_eps_s=float(kink_eps_s),
+                         kink_eps_v=float(kink_eps_v))
         ticks = C.c_int32(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.eepacc_nlp_solve(self.h, B, s_tv.data_ptr(), groups.data_ptr() if groups is not None else None, n_groups,
@@ -852,7 +854,7 @@ def pick_start(J, status, e_prim, feas_tol: float = 1e-6):
 
 
 def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts=DEFAULT_STARTS, max_iter: int | None = None,
-                 native: bool = True, fused: bool = True, restarts: int = 3):
+                 native: bool = True, fused: bool = True, restarts: int = 3, kink_eps_s: float = 1e-2):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
     gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch through
     eepacc_nlp_solve (native = False: the round-2 host loop over the single operators, kept as a cross-check).  max_iter:
@@ -880,8 +882,22 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
     st = R["status"].view(Rn, S)
     win = pick_start(R["J"].view(Rn, S), st, R["kkt"][:, 1].view(Rn, S))
     idx = torch.arange(Rn, device=win.device) * S + win
-    return dict(J=R["J"][idx], status=R["status"][idx], iters=R["iters"][idx], start=win, chi=R["chi"][idx], u=R["u"][idx],
-                all_J=R["J"].view(Rn, S), all_status=st, all_kkt=R["kkt"].view(Rn, S, -1), all_iters=R["iters"].view(Rn, S), ticks=R.get("ticks"))
+    out = dict(J=R["J"][idx].clone(), status=R["status"][idx].clone(), iters=R["iters"][idx].clone(), start=win, chi=R["chi"][idx].clone(),
+               u=R["u"][idx].clone(), all_J=R["J"].view(Rn, S), all_status=st, all_kkt=R["kkt"].view(Rn, S, -1), all_iters=R["iters"].view(Rn, S),
+               ticks=R.get("ticks"), second_phase=torch.zeros(Rn, dtype=torch.bool, device=win.device))
+    bad = torch.nonzero(out["status"] != 0).flatten()
+    if native and kink_eps_s > 0 and bad.numel():
+        # second phase (as in eepacc_run_nlp_host): routes none of whose starts reached a KKT point -- the minimiser pins a
+        # node on a table knot -- again from the forces of their best start, with the kinks of the position tables rounded
+        f2 = out["u"][bad][:, :, :2].clone()
+        f2[:, :, 1] = torch.clamp(f2[:, :, 1], max=-1e-3)
+        R2 = sol.solve_native(torch.as_tensor(s_tv_routes, device=f2.device)[bad], chi0[:bad.numel()], f2, max_iter=max_iter, mu_init=1e-2,
+                              restarts=restarts, margin=1e-1, kink_eps_s=kink_eps_s)
+        ok = R2["status"] == 0
+        tgt = bad[ok]
+        out["J"][tgt] = R2["J"][ok]; out["status"][tgt] = 0; out["iters"][tgt] += R2["iters"][ok]
+        out["chi"][tgt] = R2["chi"][ok]; out["u"][tgt] = R2["u"][ok]; out["second_phase"][tgt] = True
+    return out
 
 
 def RunOpt_NLP(OPTsettings: Dict[str, Any], V: Dict[str, float] | None = None, device: int = 0, start_forces=None,

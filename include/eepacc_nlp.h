@@ -169,6 +169,13 @@ typedef struct eepacc_nlp_options {
     double  mu_min;          /* its floor                                                                      [1e-9] */
     double  obj_scale;       /* objective scaling of the iteration (the reported objective is unscaled)        [1e-5] */
     double  margin;          /* slack margin of the start point                                                [1.0]  */
+    double  kink_eps_s;      /* > 0: eepacc_nlp_solve works on a copy of the position lookups (speed limit, curvature, stop
+                                profile, velocity incentive) whose kinks are rounded over +- this many metres (C^1: a parabola
+                                between two extra knots); 0: the exact piecewise-linear tables.  eepacc_run_nlp_host solves
+                                with the exact tables first and uses the rounded copy (0: 1e-2 m; < 0: never) only for routes
+                                none of whose starts reaches a KKT point -- measured cause: the minimiser pins a node on a knot
+                                (the end of the 1 m speed-limit ramp), where the piecewise-linear problem has no KKT point */
+    double  kink_eps_v;      /* reserved (the ISO speed tables stay exact)                                                  */
 } eepacc_nlp_options;
 
 /* Interior-point solve of B problem instances.  Every instance is one route with one start; the
@@ -196,7 +203,8 @@ int eepacc_nlp_solve(eepacc_nlp_handle* h, int B, const double* s_tv_dev, const 
  * car-following force trajectories (look-ahead samples / response time per start: eepacc_nlp_car_following_start_host)
  * solved side by side as one group, or -- start_forces_host [n_routes][N][2] given -- one warm start.
  * Outputs per route: chi_host [n_routes][N+1][4], u_host [n_routes][N][6], J_host, status_host (as eepacc_nlp_solve),
- * iters_host / NULL, start_host / NULL (index of the winning start), all_J_host / all_status_host [n_routes][n_starts] / NULL.
+ * iters_host / NULL, start_host / NULL (index of the winning start; n_starts + index when the route was solved in the
+ * second phase with rounded table kinks, see eepacc_nlp_options.kink_eps_s), all_J_host / all_status_host [n_routes][n_starts] / NULL.
  * Winner: lowest objective among the starts at a KKT point; if none, among the primal-feasible ones; else the smallest
  * constraint violation. */
 int eepacc_run_nlp_host(eepacc_nlp_handle* h, int n_routes, const double* s_tv_host, double s_init, double v_init, int n_starts,

@@ -98,7 +98,7 @@ def test_nlp_header_symbols_and_layout(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.eepacc_nlp_sizeof_problem() == C.sizeof(nlp.NlpProblemPOD)
-    assert C.sizeof(nlp.NlpOptions) == 4 * 4 + 5 * 8                     # eepacc_nlp_options: four int32, five doubles
+    assert C.sizeof(nlp.NlpOptions) == 4 * 4 + 7 * 8                     # eepacc_nlp_options: four int32, seven doubles
     if _no_gpu():
         OPT, V, s_tv, v_tv = make_case("ABO", 20)
         with pytest.raises(engine.EepaccError, match="no HIP device"):
