@@ -15,6 +15,7 @@
 
 namespace eepacc {
 size_t ab_smem_bytes(int N);
+size_t ab_hb_doubles(int N, int B, int num_cus);
 hipError_t launch_ab_step(const DevCfg* dC, int N, int variant, int B, const double* s, const double* v, const double* a_prev,
                           const double* t0, const double* s_tv, const double* v_tv, const double* a_tv_prev,
                           unsigned long long* codes, double* out, double* s_pred, double* v_pred,
@@ -43,6 +44,7 @@ struct eepacc_handle {
     DevCfg cfg;
     DevCfg* d_cfg = nullptr;
     double* d_Hinv = nullptr;
+    double* d_hb = nullptr;          // ICE variant: per-wave base inverse of the step
     double* d_pred = nullptr;                // [max_batch][2][64] previous predictions (paramEstSetting 2)
     unsigned long long* d_codes = nullptr;   // [max_batch][64]
     int32_t* d_iters = nullptr;              // [max_batch]
@@ -97,7 +99,7 @@ static bool spd_inverse(std::vector<long double>& A, int n) {
 }
 
 // kernel variant of a handle: 0 plain, 1 blocked moves, 2 baseline controller
-static int ab_variant(const DevCfg& C) { return C.bl_mode ? 2 : (C.mb_any ? 1 : 0); }
+static int ab_variant(const DevCfg& C) { return C.bl_mode ? 2 : (C.ab_fuel_term == 2 ? 3 : (C.mb_any ? 1 : 0)); }
 
 static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& C, std::vector<double>& Hinv) {
     memset(&C, 0, sizeof(C));
@@ -117,8 +119,16 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         return fail(EEPACC_EINVAL, "route table sizes out of range");
     if (S->N_integratePlant < 1) return fail(EEPACC_EINVAL, "N_integratePlant < 1");
     if (S->ab_fuel_term < 0 || S->ab_fuel_term > 2) return fail(EEPACC_EINVAL, "ab_fuel_term must be 0, 1 or 2");
-    if (S->ab_fuel_term == 2 && !S->bl_mode)
-        return fail(EEPACC_ENOTSUP, "ab_fuel_term == 2 (ICE-map fuel term, CreateQP_AB.m:154-159: step-varying Hessian) is not built");
+    if (S->ab_fuel_term == 2 && !S->bl_mode) {
+        // ICE-map fuel term (CreateQP_AB.m:154-159): step-varying Hessian, built and inverted in LDS by its own kernel variant
+        if (N > 32) return fail(EEPACC_ENOTSUP, "ab_fuel_term == 2 (ICE-map fuel term) is built for N_hor <= 32");
+        for (int k = 0; S->Mb && k < N; ++k)
+            if (S->Mb[k] != 0) return fail(EEPACC_ENOTSUP, "ab_fuel_term == 2 (ICE-map fuel term) is not built with move blocking");
+        if (!(V->tau_fd > 0.0) || !(V->eta_drive > 0.0) || !(V->R_w > 0.0))
+            return fail(EEPACC_EINVAL, "ab_fuel_term == 2 needs V.tau_fd, V.eta_drive, V.R_w > 0 (SetVehicleParameters.m:92,100-101)");
+        for (int g2 = 0; g2 < 8; ++g2) if (!(V->tau_gb[g2] > 0.0)) return fail(EEPACC_EINVAL, "ab_fuel_term == 2 needs positive gear ratios V.tau_gb");
+        for (int g2 = 1; g2 < 7; ++g2) if (!(V->upSpd[g2] >= V->upSpd[g2 - 1])) return fail(EEPACC_EINVAL, "V.upSpd must ascend");
+    }
     C.N = N;
     C.ab_fuel_term = S->ab_fuel_term; C.ab_route_rows = S->ab_route_rows;
     C.paramEstSetting = S->paramEstSetting; C.TVestSetting = S->TVestSetting;
@@ -194,6 +204,15 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
     C.cq = C.w_FC * V->p01 * V->F2;
     C.glin_v = C.bl_mode ? -bl_travel : C.w_FC * V->p10;
     C.glin_a = C.w_FC * V->p01 * V->lambda * V->m;
+    if (C.ab_fuel_term == 2) {
+        // per stage: cq_k = ice_cq / tau_k, lv_k = ice_lv tau_k, la_k = ice_la / tau_k (CreateQP_AB.m:154-159)
+        C.cq = 0.0; C.glin_v = 0.0; C.glin_a = 0.0;
+        C.ice_cq = C.w_FC * V->k01 * V->F2 * V->R_w / V->tau_fd / V->eta_drive;
+        C.ice_lv = C.w_FC * V->k10 / V->R_w * V->tau_fd;
+        C.ice_la = C.w_FC * V->k01 * V->lambda * V->m * V->R_w / V->tau_fd / V->eta_drive;
+        for (int g2 = 0; g2 < 7; ++g2) C.ice_up[g2] = V->upSpd[g2];
+        for (int g2 = 0; g2 < 8; ++g2) C.ice_gb[g2] = V->tau_gb[g2];
+    }
     C.n_speedLim = S->n_speedLim; C.n_curv = S->n_curv; C.n_slope = S->n_slope; C.n_stop = S->n_stop; C.n_TL = S->n_TL;
     for (int i = 0; i < S->n_speedLim; ++i) { C.s_speedLim[i] = S->s_speedLim[i]; C.v_speedLim[i] = S->v_speedLim[i]; }
     const double alpha = S->alpha_TTL;
@@ -276,6 +295,15 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     HIPCHK(hipMalloc(&h->d_pred, (size_t)max_batch * 128 * sizeof(double)));
     HIPCHK(hipMemset(h->d_pred, 0, (size_t)max_batch * 128 * sizeof(double)));
     C.pred = h->d_pred;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (C.ab_fuel_term == 2 && !C.bl_mode) {
+        HIPCHK(hipMalloc(&h->d_hb, eepacc::ab_hb_doubles(C.N, max_batch, h->num_cus) * sizeof(double)));
+        C.hb = h->d_hb;
+    }
     h->cfg = C;
     HIPCHK(hipMalloc(&h->d_cfg, sizeof(DevCfg)));
     HIPCHK(hipMemcpy(h->d_cfg, &C, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -297,7 +325,7 @@ extern "C" int eepacc_create(eepacc_handle** out, const eepacc_settings* S, cons
     }
     HIPCHK(eepacc::set_max_smem());
     // FBMPC: structured kernels unless the settings need the dense path (or EEPACC_FB_DENSE=1 asks for it)
-    h->fbs = eepacc::fbs_supported(C) && eepacc::fbs_smem_bytes(C.N) <= 152 * 1024;
+    h->fbs = eepacc::fbs_supported(C) && eepacc::fbs_smem_bytes(C.N) <= 160 * 1024 - 4608;
     if (const char* e = getenv("EEPACC_FB_DENSE")) if (atoi(e) != 0) h->fbs = false;
     if (h->fbs) {
         HIPCHK(eepacc::fbs_set_max_smem());
@@ -329,6 +357,7 @@ extern "C" void eepacc_destroy(eepacc_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     if (h->d_Hinv) (void)hipFree(h->d_Hinv);
+    if (h->d_hb) (void)hipFree(h->d_hb);
     if (h->d_pred) (void)hipFree(h->d_pred);
     if (h->d_codes) (void)hipFree(h->d_codes);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -604,7 +633,7 @@ extern "C" int eepacc_run_fbmpc(eepacc_handle* h, int B, int n_steps, const doub
         return fail(EEPACC_EINVAL, "eepacc_run_fbmpc after eepacc_fb_step: the per-step operator keeps no closed-loop state to resume from; call eepacc_reset first");
     if (h->fbs) {
         // work-unit length: 16 MPC steps, shorter for short launches so that every resident wave still gets several units
-        int chunk_steps = eepacc::pick_chunk_steps(n_steps, B, h->num_cus * 6);
+        int chunk_steps = eepacc::pick_chunk_steps(n_steps, B, h->num_cus * 7);
         eepacc::fbs_run_args a;
         a.cfg = h->d_cfg; a.B = B; a.k_start = h->fb_k_done; a.n_steps = n_steps;
         a.s0 = s0; a.v0 = v0; a.a_m1 = a_minus1; a.s_tv = s_tv; a.v_tv = v_tv;

@@ -70,6 +70,10 @@ struct DevCfg {
     double bl_eps;                // curvature added to an LP (w_a = w_j = 0); excluded from the reported cost
     double state_tol;             // tolerance of the hard bounds on the measured state (constant rows of stage 0)
     double bl_aLo, bl_aHi, bl_jLo, bl_jHi;   // BL_a_LimLowVel, BL_a_LimHighVel, BL_j_LimLowVel, BL_j_LimHighVel
+    // ICE-map fuel term (ab_fuel_term = 2, CreateQP_AB.m:154-159): per stage cq_k = ice_cq / tau_k, lv_k = ice_lv tau_k,
+    // la_k = ice_la / tau_k with the gear ratio tau_k = ice_gb[first g: v_est < ice_up[g]] (LUTgearshift.m:17-41)
+    double ice_cq, ice_lv, ice_la, ice_up[7], ice_gb[8];
+    double* hb;                   // device, per-wave NS x NS scratch: the step's base inverse of the ICE variant
 };
 
 }  // namespace eepacc

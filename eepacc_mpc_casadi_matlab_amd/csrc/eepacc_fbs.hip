@@ -115,20 +115,29 @@ __device__ __forceinline__ double row_aw(int t, const RC& c) {
         default: return 0.0;
     }
 }
+// Right-hand sides that are equal by construction share a slot of FMem::ba: the three force bounds (1e4 N), the two
+// torque limits, the two rear-axle limits, the two total-friction limits (CreateQP_FB.m:319-326, 359-387).
+constexpr unsigned kSlotOwner = 0x1ffffffu & ~((1u << F_FMHI) | (1u << F_FBLO) | (1u << F_TQMAX) | (1u << F_RTHI) | (1u << F_FTLO));
+constexpr int kNumSlots = 20;
+static_assert(__builtin_popcount(kSlotOwner) == kNumSlots, "slot map of the right-hand sides");
+__device__ __forceinline__ constexpr int slot_of(int t) { return __builtin_popcount(kSlotOwner & ((2u << t) - 1u)) - 1; }
+__device__ __forceinline__ constexpr bool owns_slot(int t) { return ((kSlotOwner >> t) & 1u) != 0u; }
 __device__ __forceinline__ bool is_wrow(int t) { return t >= F_FMLO && t <= F_RTHI; }
 __device__ __forceinline__ bool is_relax(int t) { return t == F_FMLO || t == F_TQMIN || t == F_RTLO; }
 
+// LDS diet of round 3 (7 instead of 6 waves per CU at N <= 32): the input vectors of the He products live in ws / wv
+// (free outside gradient_side), the pivot column of the factor updates in wa, Pi_k / Theta_k are read from the lane that
+// holds them, and row types with identical right-hand sides share a slot of `ba`.
 template <int MMAX, int NS>
 struct FMem {                 // one per wave, in LDS (followed by the wave's NS x NS matrix He)
     double P[MMAX * (MMAX + 1) / 2];
-    double yv[NS], yv2[NS], av[NS];
+    double av[NS];
     double shv[NS + 1], vhv[NS + 1];
     double ub[NS + 1], sub[NS + 1], vub[NS + 1];      // images of a vector; also scratch of adjoint()
-    double ws[NS + 1], wv[NS + 1], wa[NS + 1];
+    double ws[NS + 1], wv[NS + 1], wa[NS + 1];        // stage weights of gradient_side; yv = ws, yv2 = wv, colk = wa otherwise
     double e_al[MMAX], e_be[MMAX], e_ga[MMAX], e_de[MMAX], e_d[MMAX];
-    double lam[MMAX], sv[MMAX], rv[MMAX], colk[MMAX > NS ? MMAX : NS];
-    double Pi[NS + 2], Th[NS + 2];                    // Pi_k, Theta_k for k = 0..N
-    double ba[kNumF * (NS + 1)];                      // right-hand sides, [type][lane]
+    double lam[MMAX], sv[MMAX], rv[MMAX];
+    double ba[kNumSlots * (NS + 1)];                  // right-hand sides, [slot of the type][lane]
     int w_k[MMAX];
 };
 
@@ -164,7 +173,7 @@ __device__ __forceinline__ int lane_group(const Lane& L, int t) { return L.lane 
 __device__ __forceinline__ double group_w(const RC& c, int g) { return g == GF ? c.wF : (g == GS ? c.wS : (g == GV ? c.wV : c.wH)); }
 __device__ __forceinline__ double group_lb(const Lane& L, int g) { return g == GF ? L.lbF : (g == GS ? L.lbS : (g == GV ? L.lbV : L.lbH)); }
 
-template <int NS> __device__ __forceinline__ double ba_of(const double* ba, int t, int lane) { return ba[t * (NS + 1) + lane]; }
+template <int NS> __device__ __forceinline__ double ba_of(const double* ba, int t, int lane) { return ba[slot_of(t) * (NS + 1) + lane]; }
 
 // bit tricks on the 2-bit codes: bit 2t of the result is set where type t has the given code
 constexpr unsigned long long kEven = 0x5555555555555555ull;
@@ -249,7 +258,8 @@ __device__ __forceinline__ double adjoint(const Lane& L, const FMem<MMAX, NS>& M
     const int k = N - r;
     const bool in = k >= 0;
     const double s = in ? ws[k] : 0.0;
-    const double x = in ? fma(M.Pi[k], wv[k], M.Th[k] * s) : 0.0;
+    const double Pik = __shfl(L.Pi, in ? k : 0, 64), Thk = __shfl(L.Th, in ? k : 0, 64);      // Pi_k, Theta_k live on lane k
+    const double x = in ? fma(Pik, wv[k], Thk * s) : 0.0;
     const double S0 = scan_excl(s), S1 = scan_excl(x);
     if (in) { tmp[k] = S0; tmp[(NS + 1) + k] = S1; }
     WSYNC();
@@ -333,10 +343,10 @@ template <int MMAX, int NS>
 __device__ __forceinline__ void he_rank1(const Lane& L, const RC& c, FMem<MMAX, NS>& M, double* He, int k, bool add) {
     const int lane = L.lane, N = L.N;
     const double chwk = bcast(L.chw, k);
-    const double nk = normal_at(L, k, 1.0, chwk, 0.0, 0.0, M.Pi[k], M.Th[k]);
-    if (lane < NS) M.yv[lane] = nk;
+    const double nk = normal_at(L, k, 1.0, chwk, 0.0, 0.0, bcast(L.Pi, k), bcast(L.Th, k));
+    if (lane < NS) M.ws[lane] = nk;
     WSYNC();
-    const double y = hinv_mul<NS>(He, M.yv, N, lane);
+    const double y = hinv_mul<NS>(He, M.ws, N, lane);
     double sy, vy;
     hom_traj(L, y, sy, vy);
     const double ny = bcast(sy + chwk * vy, k);
@@ -363,13 +373,13 @@ template <int MMAX, int NS>
 __device__ __forceinline__ bool he_rank2(const Lane& L, const RC& c, FMem<MMAX, NS>& M, double* He, int k,
                                          double fal, double fbe, double fga, double fde, bool add) {
     const int lane = L.lane, N = L.N;
-    const double Pk = M.Pi[k], Tk = M.Th[k];
+    const double Pk = bcast(L.Pi, k), Tk = bcast(L.Th, k);
     const double sg = normal_at(L, k, 0.0, 1.0, 0.0, 0.0, Pk, Tk);
     const double fv = normal_at(L, k, fal, fbe, fga, fde, Pk, Tk);
-    if (lane < NS) { M.yv[lane] = sg; M.yv2[lane] = fv; }
+    if (lane < NS) { M.ws[lane] = sg; M.wv[lane] = fv; }
     WSYNC();
     double y1, y2;
-    hinv_mul2<NS>(He, M.yv, M.yv2, N, lane, y1, y2);
+    hinv_mul2<NS>(He, M.ws, M.wv, N, lane, y1, y2);
     double s1, v1, s2, v2;
     hom_traj(L, y1, s1, v1);
     hom_traj(L, y2, s2, v2);
@@ -502,9 +512,9 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMA
     }
     if (F.fast == 2 && m == F.m_old - 1) {
         const int p = F.drop_pos, mo = F.m_old;
-        if (lane < mo) M.colk[lane] = M.P[pidx(lane, p)];
+        if (lane < mo) M.wa[lane] = M.P[pidx(lane, p)];
         WSYNC();
-        const double ip = 1.0 / M.colk[p];
+        const double ip = 1.0 / M.wa[p];
         const int nnz = m * (m + 1) / 2;
         for (int e0 = 0; e0 < nnz; e0 += 64) {
             const int e = e0 + lane;
@@ -512,7 +522,7 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMA
             if (e < nnz) {
                 const int code = rc[e], r = code >> 8, cc = code & 255;
                 const int i = r < p ? r : r + 1, j = cc < p ? cc : cc + 1;
-                v = M.P[pidx(i, j)] - M.colk[i] * M.colk[j] * ip;
+                v = M.P[pidx(i, j)] - M.wa[i] * M.wa[j] * ip;
             }
             WSYNC();
             if (e < nnz) M.P[e] = v;
@@ -531,12 +541,12 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMA
             const bool two = j + 1 < m;
             const int j1 = two ? j + 1 : j;
             const int kj0 = M.w_k[j], kj1 = M.w_k[j1];
-            const double c0 = normal_at(L, kj0, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], M.Pi[kj0], M.Th[kj0]);
-            const double c1 = normal_at(L, kj1, M.e_al[j1], M.e_be[j1], M.e_ga[j1], M.e_de[j1], M.Pi[kj1], M.Th[kj1]);
-            if (lane < NS) { M.yv[lane] = c0; M.yv2[lane] = c1; }
+            const double c0 = normal_at(L, kj0, M.e_al[j], M.e_be[j], M.e_ga[j], M.e_de[j], bcast(L.Pi, kj0), bcast(L.Th, kj0));
+            const double c1 = normal_at(L, kj1, M.e_al[j1], M.e_be[j1], M.e_ga[j1], M.e_de[j1], bcast(L.Pi, kj1), bcast(L.Th, kj1));
+            if (lane < NS) { M.ws[lane] = c0; M.wv[lane] = c1; }
             WSYNC();
             double u0, u1;
-            hinv_mul2<NS>(Hs, M.yv, M.yv2, N, lane, u0, u1);
+            hinv_mul2<NS>(Hs, M.ws, M.wv, N, lane, u0, u1);
             WSYNC();
             double su0, vu0, su1, vu1;
             hom_traj(L, u0, su0, vu0);
@@ -556,13 +566,13 @@ __device__ __forceinline__ int rebuild_and_factor(Lane& L, const RC& c, FMem<MMA
         const double d = M.P[pidx(k, k)];
         if (!(d > 1e-12 * M.sv[k])) { singular = 1; break; }
         const double inv = 1.0 / d;
-        if (lane < m) M.colk[lane] = M.P[pidx(lane, k)];
+        if (lane < m) M.wa[lane] = M.P[pidx(lane, k)];
         WSYNC();
 #pragma unroll 2
         for (int e = lane; e < nnz; e += 64) {
             const int code = rc[e], r = code >> 8, cc = code & 255;
-            const double c0 = M.colk[r];
-            const double cl = M.colk[cc] * inv;
+            const double c0 = M.wa[r];
+            const double cl = M.wa[cc] * inv;
             double v0 = M.P[e] - c0 * cl;
             if (cc == k) v0 = c0 * inv;
             if (r == k) v0 = (cc == k) ? -inv : cl;
@@ -657,9 +667,9 @@ __device__ __forceinline__ void primal_from_multipliers(Lane& L, const RC& c, FM
                                                         double lam_q, const Incoming& q, double& grad_total) {
     const double g = gradient_side(L, c, M, m, &lg, M.lam, lam_q, q.kq, q.al, q.be, q.ga, q.de);
     grad_total = g;
-    if (L.lane < NS) M.yv[L.lane] = g;
+    if (L.lane < NS) M.ws[L.lane] = g;
     WSYNC();
-    L.u = -hinv_mul<NS>(Hs, M.yv, L.N, L.lane);
+    L.u = -hinv_mul<NS>(Hs, M.ws, L.N, L.lane);
     hom_traj(L, L.u, L.sh, L.vh);
     L.um1 = lane_prev(L.u);
     if (L.lane < L.N) M.av[L.lane] = L.u;
@@ -922,9 +932,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         local_gradient<NS>(L, c, M.ba, lg.s, lg.v, lg.a0, lg.a1);
         if (m > 0) {
             const double g = gradient_side(L, c, M, 0, &lg, nullptr, lam_q, q.kq, q.al, q.be, q.ga, q.de);
-            if (lane < NS) M.yv[lane] = g;
+            if (lane < NS) M.ws[lane] = g;
             WSYNC();
-            const double h = hinv_mul<NS>(Hs, M.yv, N, lane);
+            const double h = hinv_mul<NS>(Hs, M.ws, N, lane);
             double shh, vhh;
             hom_traj(L, h, shh, vhh);
             if (lane < N) M.ub[lane] = h;
@@ -973,10 +983,10 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
         if (kq < N) viol += q.ga * M.av[kq];
         if (kq > 0) viol += q.de * M.av[kq - 1];
         // u = He c_q and its trajectories
-        const double cj = normal_at(L, kq, q.al, q.be, q.ga, q.de, M.Pi[kq], M.Th[kq]);
-        if (lane < NS) M.yv[lane] = cj;
+        const double cj = normal_at(L, kq, q.al, q.be, q.ga, q.de, bcast(L.Pi, kq), bcast(L.Th, kq));
+        if (lane < NS) M.ws[lane] = cj;
         WSYNC();
-        const double ud = hinv_mul<NS>(Hs, M.yv, N, lane);
+        const double ud = hinv_mul<NS>(Hs, M.ws, N, lane);
         double su, vu;
         hom_traj(L, ud, su, vu);
         if (lane < N) M.ub[lane] = ud;
@@ -1009,9 +1019,9 @@ __device__ __forceinline__ SolveStats solve_qp(Lane& L, const RC& c, FMem<MMAX, 
             double vz = vu;
             if (m > 0) {
                 const double gz = gradient_side(L, c, M, m, nullptr, M.rv, 0.0, 0, 0.0, 0.0, 0.0, 0.0);
-                if (lane < NS) M.yv[lane] = gz;
+                if (lane < NS) M.ws[lane] = gz;
                 WSYNC();
-                const double hz = hinv_mul<NS>(Hs, M.yv, N, lane);
+                const double hz = hinv_mul<NS>(Hs, M.ws, N, lane);
                 double sz, vzz;
                 hom_traj(L, hz, sz, vzz);
                 vz = vu - vzz;
@@ -1282,7 +1292,6 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
     L.Th1 = L.Th + (lane < N ? L.T * L.Pi : 0.0);
     L.gam = lane < N ? (L.T / lm) / Pi1 : 0.0;
     if (lane > N) L.Pi = 0.0;
-    if (lane <= N) { M.Pi[lane] = L.Pi; M.Th[lane] = L.Th; }
     // free response: vbar_k = Pi_k (v_0 + sum_{i<k} D2_i / Pi_{i+1}), sbar_k = s_0 + sum_{i<k} T_i vbar_i
     L.vbar = L.Pi * (in.v + scan_excl(lane < N ? d2 / Pi1 : 0.0));
     const double sbar = in.s + scan_excl(lane < N ? L.T * L.vbar : 0.0);
@@ -1385,15 +1394,15 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
             const double d = Hs[k * NS + k];
             if (!(d > 0.0)) { h_bad = 1; break; }
             const double inv = 1.0 / d;
-            if (lane < NS) M.colk[lane] = (lane < N) ? Hs[k * NS + lane] : 0.0;
+            if (lane < NS) M.wa[lane] = (lane < N) ? Hs[k * NS + lane] : 0.0;
             WSYNC();
-            const double hkj = M.colk[jcol];
+            const double hkj = M.wa[jcol];
             const double f = hkj * inv;
             const bool piv = jcol == k;
 #pragma unroll
             for (int ii = 0; ii < RPL; ++ii) {
                 const int i = r0 + ii;
-                const double ck = M.colk[i], old = col[i * NS];
+                const double ck = M.wa[i], old = col[i * NS];
                 const double upd = piv ? ck * inv : fma(-ck, f, old);
                 col[i * NS] = (i == k) ? (piv ? -inv : f) : upd;
             }
@@ -1435,7 +1444,7 @@ __device__ __forceinline__ void fb_step(const DevCfg& C, FMem<MMAX, NS>& M, doub
         for (int t = 0; t < kNumF; ++t) {
             const double al = row_al(t), be = row_be(t, c, L.chw);
             const double bat = b[t] - al * sbar - be * L.vbar;
-            if (lane <= N) M.ba[t * (NS + 1) + lane] = bat;
+            if (owns_slot(t) && lane <= N) M.ba[slot_of(t) * (NS + 1) + lane] = bat;
             bool exists;
             if (lane < N) {
                 exists = true;
@@ -1630,7 +1639,7 @@ k_fbs_step(fbs_step_args a) {
 // B1: closed loop over n_steps for B instances (ABO/RunOpt_FBMPC.m:161-331); work units (instance, chunk of MPC
 // steps) handed out through a device-wide counter as in the ABMPC kernel (eepacc_ab_impl.inc, k_run_abmpc)
 template <int MMAX, int NS, int WPB>
-__global__ void __launch_bounds__(64 * WPB, (NS <= 32 ? 2 : 1))
+__global__ void __launch_bounds__(64 * WPB, ((NS <= 32 && WPB <= 2) ? 2 : 1))
 k_fbs_run(fbs_run_args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevCfg& C = *a.cfg;
@@ -1751,7 +1760,8 @@ extern "C" int eepacc_debug_fbs_prof(unsigned long long* out, int reset) {
 
 // ----------------------------------------------------------------------------------------------
 // host-side launchers used by eepacc_capi.cpp
-constexpr int kFMMaxSmall = 34, kFNSSmall = 32, kFWpbSmall = 2;     // N <= 32
+constexpr int kFMMaxSmall = 32, kFNSSmall = 32, kFWpbSmall = 7;     // N <= 32: 21.7 KB of LDS per wave, one block of 7 waves per CU
+                                                                    // (working-set rows are independent in the N-dimensional u-space: m <= N)
 constexpr int kFMMaxLarge = 66, kFNSLarge = 64, kFWpbLarge = 1;     // N <= 63
 
 // settings the structured solver represents; everything else goes through the dense path (eepacc_fb.hip)
@@ -1769,9 +1779,12 @@ size_t fbs_smem_bytes(int N) {
                           : fbs::wave_bytes(sizeof(fbs::FMem<kFMMaxLarge, kFNSLarge>), kFNSLarge) * kFWpbLarge;
 }
 
+// dynamic LDS a block may ask for: 160 KB per CU minus the kernels' static index table (one ushort per packed entry of P)
+constexpr size_t kFbsLdsBudget = 160 * 1024 - 4608;
+
 static int fbs_run_grid(int N, int n_units, int num_cus) {
     const size_t smem = fbs_smem_bytes(N);
-    int per_cu = (int)((152 * 1024) / smem);
+    int per_cu = (int)((kFbsLdsBudget) / smem);
     if (per_cu < 1) per_cu = 1;
     const int wpb = N > kFNSSmall ? kFWpbLarge : kFWpbSmall;
     int grid = num_cus * per_cu;
@@ -1794,7 +1807,7 @@ hipError_t fbs_set_max_smem() {
                           reinterpret_cast<const void*>(&fbs::k_fbs_run<kFMMaxSmall, kFNSSmall, kFWpbSmall>),
                           reinterpret_cast<const void*>(&fbs::k_fbs_run<kFMMaxLarge, kFNSLarge, kFWpbLarge>)};
     for (int i = 0; i < 4; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFbsLdsBudget);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

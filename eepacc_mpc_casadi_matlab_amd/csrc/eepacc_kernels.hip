@@ -37,6 +37,17 @@
 #undef EEPACC_IMPL_MB
 #undef EEPACC_IMPL_BL
 
+// ICE-map fuel term (CreateQP_AB.m:154-159): step-varying Hessian, built and inverted in LDS every step
+#define EEPACC_IMPL_NS ice
+#define EEPACC_IMPL_MB false
+#define EEPACC_IMPL_BL false
+#define EEPACC_IMPL_ICE true
+#include "eepacc_ab_impl.inc"
+#undef EEPACC_IMPL_NS
+#undef EEPACC_IMPL_MB
+#undef EEPACC_IMPL_BL
+#undef EEPACC_IMPL_ICE
+
 // ----------------------------------------------------------------------------------------------
 // host-side launchers used by eepacc_capi.cpp
 namespace eepacc {
@@ -77,7 +88,8 @@ size_t ab_smem_bytes(int N) {
 #define EEPACC_LAUNCH_NS(NSP, KERNEL, MM, NSV, WPB, GRID, ...)                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(NSP::KERNEL<MM, NSV, WPB>), dim3(GRID), dim3(64 * WPB), ab_smem_bytes(N), stream, __VA_ARGS__)
 #define EEPACC_LAUNCH(KERNEL, MM, NSV, WPB, GRID, ...)                                                        \
-    do { if (variant == 2) EEPACC_LAUNCH_NS(blc, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);                    \
+    do { if (variant == 3) EEPACC_LAUNCH_NS(ice, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);                    \
+         else if (variant == 2) EEPACC_LAUNCH_NS(blc, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);               \
          else if (variant == 1) EEPACC_LAUNCH_NS(withmb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__);            \
          else EEPACC_LAUNCH_NS(nomb, KERNEL, MM, NSV, WPB, GRID, __VA_ARGS__); } while (0)
 
@@ -93,6 +105,13 @@ int pick_chunk_steps(int n_steps, int B, int resident_waves) {
     long long per = ((long long)n_steps * B) / (8LL * (resident_waves > 0 ? resident_waves : 1));
     int c = per > kChunkStepsDefault ? kChunkStepsDefault : (int)per;
     return c < 2 ? 2 : c;
+}
+
+// per-wave scratch of the ICE variant (base inverse of the step): one NS x NS block for every wave a launch can have
+size_t ab_hb_doubles(int N, int B, int num_cus) {
+    if (N > kNSSmall) return 0;
+    const size_t step_waves = (size_t)((B + 3) / 4) * 4, run_waves = (size_t)num_cus * kBlocksSmall * 4;
+    return (step_waves > run_waves ? step_waves : run_waves) * kNSSmall * kNSSmall;
 }
 
 hipError_t launch_ab_step(const DevCfg* dC, int N, int variant, int B, const double* s, const double* v, const double* a_prev,
@@ -142,7 +161,7 @@ hipError_t launch_postprocess(const DevCfg* dC, int B, int n_steps, const double
 }
 
 hipError_t set_max_smem() {
-    const void* fns[12] = {reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
+    const void* fns[16] = {reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&nomb::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&nomb::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>),
@@ -153,8 +172,12 @@ hipError_t set_max_smem() {
                           reinterpret_cast<const void*>(&blc::k_ab_step<kMMaxSmall, kNSSmall, 4>),
                           reinterpret_cast<const void*>(&blc::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
                           reinterpret_cast<const void*>(&blc::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
-                          reinterpret_cast<const void*>(&blc::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>)};
-    for (int i = 0; i < 12; ++i) {
+                          reinterpret_cast<const void*>(&blc::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>),
+                          reinterpret_cast<const void*>(&ice::k_ab_step<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&ice::k_ab_step<kMMaxLarge, kNSLarge, kWpbLarge>),
+                          reinterpret_cast<const void*>(&ice::k_run_abmpc<kMMaxSmall, kNSSmall, 4>),
+                          reinterpret_cast<const void*>(&ice::k_run_abmpc<kMMaxLarge, kNSLarge, kWpbLarge>)};
+    for (int i = 0; i < 16; ++i) {
         // 160 KB of LDS per CU minus the kernel's static index table (one ushort per packed entry of P)
         const int mm = (i & 1) ? kMMaxLarge : kMMaxSmall;
         const int dyn = 160 * 1024 - ((mm * (mm + 1) / 2 * 2 + 255) & ~255);

@@ -123,6 +123,9 @@ static void emx_read_inputs(const mxArray* O, int fb, eepacc_mex_inputs* in) {
         if (W) {
             if (n != 6 && n != 7) mexErrMsgIdAndTxt("eepacc:badField", "W_AB must have 6 (ORIG) or 7 (ABO) entries");
             S->ab_fuel_term = (n == 7);
+            /* extension: OPTsettings.ab_fuel_term = 2 selects the ICE-map fuel term the reference keeps commented in
+             * CreateQP_AB.m:154-159 (what savedABMPCsolICEMAP.mat was written with) */
+            if (n == 7) S->ab_fuel_term = (int)emx_scalar_opt(O, "ab_fuel_term", 1.0);
             S->ab_route_rows = (n == 6);           /* ORIG keeps the speed-limit / curve / stop / TL rows (CreateQP_AB.m:324-346) */
             for (int i = 0; i < 7; ++i) S->W_AB[i] = (n == 7) ? W[i] : (i ? W[i - 1] : 0.0);
             if (!fb) { in->nW = n; memcpy(in->W, W, sizeof(double) * (size_t)n); }

@@ -6,7 +6,7 @@ accelerations 1e-9 (absolute, SI units); positions 1e-8 m; forces 1e-6 N; QP cos
 import numpy as np
 import pytest
 
-from conftest import make_case, load_golden, golden_step_inputs, GOLDEN_AB_VARIANTS
+from conftest import make_case, load_golden, golden_step_inputs, GOLDEN_AB_VARIANTS, GOLDEN_AB_ICEMAP
 from eepacc_mpc_casadi_matlab_amd._abi import OUT, OUT_N
 from eepacc_mpc_casadi_matlab_amd.scenarios import make_s1, make_s2
 
@@ -98,6 +98,55 @@ def test_golden_weight_variants(name, torch_mod):
         assert np.abs(tr[:, OUT[n], 0] - G[n + "_opt"]).max() < 10 * tol[n], n
     E = eng.postprocess(traj)[3].cpu().numpy()[:, 0]
     assert abs(E[-1] - G["E_opt"][-1]) < 1e-9 * abs(G["E_opt"][-1])
+
+
+def test_golden_icemap_step_varying_hessian(torch_mod, lead_trace):
+    """savedABMPCsolICEMAP.mat: ABMPC with the ICE-map fuel term (CreateQP_AB.m:154-159).  The gear ratio of every horizon
+    stage follows the estimated speed (LUTgearshift.m), so the condensed Hessian changes from step to step: the kernel
+    variant `ice` builds it from closed forms and inverts it in LDS every step.  All 871 saved steps as cold QPs and as one
+    closed loop against the golden; S2 scenarios at N = 30 against the oracle (gears 1-5 along the horizon)."""
+    from oracle import Oracle
+    OPT, V, s_tv, v_tv = make_case("ABO", 20)
+    OPT = dict(OPT); OPT["W_AB"] = np.array(GOLDEN_AB_ICEMAP["W_AB"]); OPT["fuel_map"] = GOLDEN_AB_ICEMAP["fuel_map"]
+    G = load_golden("abo_abmpc_icemap")
+    eng = _engine(OPT, V)
+    c = _cols([golden_step_inputs(G, s_tv, v_tv, k) for k in range(871)])
+    out, sp, vp, status = eng.ab_step(**c)
+    o = out.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    tol = dict(TOL, Fm=1e-5, Fb=1e-5)                # weights up to 1e7: forces to 1e-5 N (as the other weight variants)
+    for n in ("xi_v", "xi_h", "xi_s", "xi_f", "Fm", "Fb", "a", "DistHor"):
+        g = G[n if n == "DistHor" else n + "_opt"]
+        assert np.abs(o[OUT[n]] - g).max() < tol[n], n
+    B = 3
+    stv = np.repeat(s_tv[:871, None], B, 1); vtv = np.repeat(v_tv[:871, None], B, 1)
+    traj, status = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv, vtv)
+    eng.synchronize()
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    assert np.abs(tr - tr[:, :, :1]).max() == 0.0
+    for n in ("s", "v", "xi_v", "xi_h", "xi_s", "xi_f", "Fm", "Fb", "a"):
+        assert np.abs(tr[:, OUT[n], 0] - G[n + "_opt"]).max() < 10 * tol[n], n
+    E = eng.postprocess(traj)[3].cpu().numpy()[:, 0]
+    assert abs(E[-1] - G["E_opt"][-1]) < 1e-9 * abs(G["E_opt"][-1])
+    # N = 30, S2 scenarios, against the oracle's closed loop
+    OPT30, V30, _, _ = make_case("ABO", 30)
+    OPT30 = dict(OPT30); OPT30["W_AB"] = np.array(GOLDEN_AB_ICEMAP["W_AB"]); OPT30["fuel_map"] = "ICE"
+    Bs, n_steps = 6, 100
+    sc = make_s2(Bs, n_steps, lead_trace["V_TO_2Hz"])
+    eng30 = _engine(OPT30, V30, 8)
+    traj, status = eng30.run_abmpc(sc["s0"], sc["v0"], sc["a_minus1"], sc["s_tv"], sc["v_tv"])
+    tr = traj.cpu().numpy()
+    assert int(status.cpu().numpy().sum()) == 0
+    orc = Oracle(OPT30, V30)
+    gears = set()
+    for i in range(Bs):
+        ref, st, _ = orc.run("ab", n_steps, 0.0, float(sc["v0"][i]), 0.0, sc["s_tv"][:, i].copy(), sc["v_tv"][:, i].copy())
+        assert st.sum() == 0
+        for n in ("s", "v", "Fm", "Fb", "a", "xi_v", "xi_h", "xi_s", "xi_f"):
+            assert np.abs(tr[:, OUT[n], i] - ref[:, OUT[n]]).max() < 10 * tol[n], (i, n)
+        gears |= {orc.lib_lut(v) for v in ref[:, OUT["v"]]}
+    assert len(gears) >= 3, gears
 
 
 @pytest.mark.parametrize("tree,N,B", [("ABO", 20, 192), ("ABO", 30, 96), ("ORIG", 30, 48), ("ABO", 60, 12)])
