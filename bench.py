@@ -47,12 +47,8 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
     t0 = time.perf_counter()
     done = sum(one(i) for i in range(n_inst))
     dt = time.perf_counter() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)                 # every core of the affinity mask (a one-GPU box offers 16 of the host's 256)
-    n_all = min(2 * cores, sc["v0"].shape[0])
+    cores, cores_source = host_cores()
+    n_all = min(4 * cores, sc["v0"].shape[0])
     t1 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         done_all = sum(ex.map(one, range(n_all)))
@@ -60,8 +56,33 @@ def cpu_baseline(OPT, V, sc, kind="ab", n_inst=8, n_steps=200):
     return dict(value=done / dt, unit="QP steps/s", cores=1, kind="port",
                 sample="%d S2 instances x %d closed-loop %sMPC steps, N=%d (oracle: literal dense condensing + dense dual active set, gcc -O3, 1 thread)"
                        % (n_inst, n_steps, "BL" if OPT.get("bl_mode") else kind.upper(), OPT["N_hor"]),
-                all_cores={"value": done_all / dt_all, "cores": cores, "cores_source": "len(os.sched_getaffinity(0))",
+                all_cores={"value": done_all / dt_all, "cores": cores, "cores_source": cores_source,
                            "sample": "%d instances x %d steps, one instance per thread" % (n_all, n_steps)})
+
+
+def host_cores():
+    """Host cores this job may use: the affinity mask, capped by the cgroup CPU quota (a one-GPU box shows all 256 cores of
+    the host in its mask but grants 16 of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+        src = "len(os.sched_getaffinity(0))"
+    except AttributeError:
+        n, src = (os.cpu_count() or 1), "os.cpu_count()"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(round(float(quota) / period)))
+                if q < n:
+                    n, src = q, "cgroup CPU quota (%s) below the affinity mask" % path
+            break
+        except Exception:
+            continue
+    return max(1, n), src
 
 
 def source_hash():
@@ -367,6 +388,7 @@ def secondary_measurements(args):
     try:
         a = copy.copy(args)
         a.workload, a.batch, a.steps, a.warmup = "nlp", NLP_SECONDARY_ROUTES, 1, 0
+        a.nlp_max_iter = 1500              # bounds the wall time of this entry (the workload's own limit is NLPmaxIter = 5000)
         t0 = time.perf_counter()
         r = run_nlp_bench(a)
         out["nlp_%droutes" % NLP_SECONDARY_ROUTES] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "solver", "reference")}
@@ -376,7 +398,8 @@ def secondary_measurements(args):
     return out
 
 
-NLP_SECONDARY_ROUTES = 4            # BASELINE configs[4] asks 128 routes per GPU; the default command's budget fits this many
+NLP_SECONDARY_ROUTES = 16           # BASELINE configs[4] asks 128 routes per GPU (profiles/r03_bench_nlp128.json: 128 of 128 in 125 s);
+                                    # the default command carries 16 of them with the iteration limit 1500
 
 
 NLP_STARTS = ((90, 4.0), (120, 2.0), (200, 2.0), (120, 4.0), (300, 2.0), (160, 8.0), (120, 8.0), (60, 2.0))
@@ -414,7 +437,8 @@ def run_nlp_bench(args, make_solver=None, device=None, backend=None):
         def make_solver(OPT_, V_, dev_):
             from eepacc_mpc_casadi_matlab_amd.nlp import NlpSolver, solve_routes
             sol = NlpSolver(OPT_, V_, device=dev_)
-            return lambda tr: solve_routes(sol, OPT_, V_, tr, NLP_STARTS, max_iter=int(OPT_.get("NLPmaxIter", 5000)))
+            mi = int(getattr(args, "nlp_max_iter", 0) or OPT_.get("NLPmaxIter", 5000))
+            return lambda tr: solve_routes(sol, OPT_, V_, tr, NLP_STARTS, max_iter=mi)
     solve = make_solver(OPT, V, dev)
 
     def sync():
