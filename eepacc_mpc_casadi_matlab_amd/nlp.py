@@ -214,7 +214,7 @@ def _bind(lib):
 
 class NlpOptions(C.Structure):
     """include/eepacc_nlp.h: eepacc_nlp_options (zero / negative entries select the library's defaults)"""
-    _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("max_ls", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("max_ls", C.c_int32), ("phase1_iter", C.c_int32),
                 ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double), ("obj_scale", C.c_double), ("margin", C.c_double),
                 ("kink_eps_s", C.c_double), ("kink_eps_v", C.c_double)]
 
@@ -854,7 +854,7 @@ def pick_start(J, status, e_prim, feas_tol: float = 1e-6):
 
 
 def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, float], s_tv_routes, starts=DEFAULT_STARTS, max_iter: int | None = None,
-                 native: bool = True, fused: bool = True, restarts: int = 3, kink_eps_s: float = 1e-2):
+                 native: bool = True, fused: bool = True, restarts: int = 3, kink_eps_s: float = 1e-2, phase1_iter: int = 1500):
     """Cold-start solve of R routes that share the route tables of `sol` and differ in their lead trace [R][N]: every route
     gets the multi-start of RunOpt_NLP (len(starts) instances, one group), all R * S instances run as one batch through
     eepacc_nlp_solve (native = False: the round-2 host loop over the single operators, kept as a cross-check).  max_iter:
@@ -874,8 +874,10 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
                                  tau=np.tile([float(tc) for (_, tc) in starts], Rn))
     groups = np.repeat(np.arange(Rn), S)
     chi0 = np.tile(np.array([[s0, v0, p0, 0.0]]), (Rn * S, 1))
+    two_phase = native and kink_eps_s > 0
+    it1 = min(max_iter, phase1_iter) if two_phase else max_iter          # as eepacc_run_nlp_host: first phase on the exact tables
     if native:
-        R = sol.solve_native(stv, chi0, forces, groups=groups, max_iter=max_iter, mu_init=1.0, restarts=restarts, margin=1.0)
+        R = sol.solve_native(stv, chi0, forces, groups=groups, max_iter=it1, mu_init=1.0, restarts=restarts, margin=1.0)
     else:
         chi, u = sol.start_from_controls(stv, chi0, forces, margin=1.0)
         R = sol.solve(stv, chi, u, max_iter=max_iter, mu_init=1.0, groups=groups, fused=fused, restarts=restarts)
@@ -891,7 +893,7 @@ def solve_routes(sol: "NlpSolver", OPTsettings: Dict[str, Any], V: Dict[str, flo
         # node on a table knot -- again from the forces of their best start, with the kinks of the position tables rounded
         f2 = out["u"][bad][:, :, :2].clone()
         f2[:, :, 1] = torch.clamp(f2[:, :, 1], max=-1e-3)
-        R2 = sol.solve_native(torch.as_tensor(s_tv_routes, device=f2.device)[bad], chi0[:bad.numel()], f2, max_iter=max_iter, mu_init=1e-2,
+        R2 = sol.solve_native(torch.as_tensor(s_tv_routes, device=f2.device)[bad], chi0[:bad.numel()], f2, max_iter=max(max_iter - it1, 1500), mu_init=1e-2,
                               restarts=restarts, margin=1e-1, kink_eps_s=kink_eps_s)
         ok = R2["status"] == 0
         tgt = bad[ok]

@@ -163,7 +163,8 @@ typedef struct eepacc_nlp_options {
     int32_t max_iter;        /* OPTsettings.NLPmaxIter (RunOpt_NLP.m:247)                                      [1500] */
     int32_t restarts;        /* re-centrings of a route whose line search fails at every Levenberg term; < 0:   [3]    */
     int32_t max_ls;          /* step halvings per factorisation                                                [4]    */
-    int32_t pad;
+    int32_t phase1_iter;     /* eepacc_run_nlp_host: iteration budget of the first phase (exact tables); routes without a KKT
+                                point after it continue in the second phase (kink_eps_s) with the rest of max_iter  [1500] */
     double  tol;             /* KKT tolerance: dual residual, constraint violation, complementarity            [1e-7] */
     double  mu_init;         /* first barrier parameter                                                        [1.0]  */
     double  mu_min;          /* its floor                                                                      [1e-9] */

@@ -441,7 +441,7 @@ def test_run_nlp_host_routes_and_iteration_limit():
         ok = R["all_status"][r] == 0
         assert ok.any() and R["J"][r] == R["all_J"][r][ok].min() and R["all_status"][r][R["start"][r]] == 0
     assert len({round(float(x), 2) for x in R["J"]}) == 3
-    R2 = sol.run_host(stv[:1], 0.0, 0.0, starts=starts[:1], max_iter=3)
+    R2 = sol.run_host(stv[:1], 0.0, 0.0, starts=starts[:1], max_iter=3, kink_eps_s=-1.0)       # (no second phase)
     assert R2["status"].tolist() == [1] and R2["iters"].tolist() == [3]
 
 
