@@ -52,7 +52,7 @@ class SettingsPOD(C.Structure):
         ("n_TL", C.c_int32), ("TLLoc", c_double_p),
         ("stopRefDist", C.c_double), ("stopRefVelSlope", C.c_double), ("stopVel", C.c_double),
         ("TLstopVel", C.c_double), ("TLStopRegionSize", C.c_double), ("alpha_TTL", C.c_double),
-        ("bl_mode", C.c_int32), ("bl_pad", C.c_int32),
+        ("bl_mode", C.c_int32), ("bl_prox_iter", C.c_int32),
         ("W_BL", C.c_double * 4),
         ("BL_a_LimLowVel", C.c_double), ("BL_a_LimHighVel", C.c_double),
         ("BL_j_LimLowVel", C.c_double), ("BL_j_LimHighVel", C.c_double),
@@ -138,6 +138,7 @@ class SettingsHolder:
             p.BL_a_LimLowVel = float(OPT["BL_a_LimLowVel"]); p.BL_a_LimHighVel = float(OPT["BL_a_LimHighVel"])
             p.BL_j_LimLowVel = float(OPT["BL_j_LimLowVel"]); p.BL_j_LimHighVel = float(OPT["BL_j_LimHighVel"])
             p.bl_lp_eps = float(OPT.get("bl_lp_eps", 0.0))
+            p.bl_prox_iter = int(OPT.get("bl_prox_iter", 0))
 
     def _dptr(self, arr, n=None):
         a = np.ascontiguousarray(arr, dtype=np.float64).ravel()

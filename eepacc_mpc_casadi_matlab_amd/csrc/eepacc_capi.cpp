@@ -189,7 +189,9 @@ static int build_cfg(const eepacc_settings* S, const eepacc_vehicle* V, DevCfg& 
         C.w_FC = 0.0; C.w_a = S->W_BL[1]; C.w_j = S->W_BL[2]; C.w_f = S->W_BL[3];
         C.w_v = 0.0; C.w_s = 0.0; C.w_h = 1.0;              // groups that do not exist in the baseline QP
         bl_travel = S->W_BL[0];
-        C.bl_eps = (C.w_a == 0.0 && C.w_j == 0.0) ? (S->bl_lp_eps > 0.0 ? S->bl_lp_eps : 1e-4) : 0.0;
+        C.bl_eps = (C.w_a == 0.0 && C.w_j == 0.0) ? (S->bl_lp_eps > 0.0 ? S->bl_lp_eps : 0.1) : 0.0;
+        if (const char* ev = getenv("EEPACC_DEBUG_BL_EPS")) { if (C.bl_eps > 0.0 && atof(ev) > 0.0) C.bl_eps = atof(ev); }
+        C.bl_prox_max = C.bl_eps > 0.0 ? (S->bl_prox_iter == 0 ? 40 : (S->bl_prox_iter < 0 ? 0 : S->bl_prox_iter)) : 0;
         C.bl_aLo = S->BL_a_LimLowVel; C.bl_aHi = S->BL_a_LimHighVel; C.bl_jLo = S->BL_j_LimLowVel; C.bl_jHi = S->BL_j_LimHighVel;
         if (!(C.bl_aLo > 0) || !(C.bl_aHi > 0) || !(C.bl_jLo > 0) || !(C.bl_jHi > 0))
             return fail(EEPACC_EINVAL, "baseline acceleration / jerk limits must be positive");

@@ -66,8 +66,8 @@ struct DevCfg {
     int32_t fb_row0[kMaxN + 2];
     int32_t mb_mask[kMaxN + 1];
     // baseline controller (RunOpt_BLMPC / CreateQP_BL): one slack group, travel incentive -w_v sum v_k
-    int32_t bl_mode, bl_pad;
-    double bl_eps;                // curvature added to an LP (w_a = w_j = 0); excluded from the reported cost
+    int32_t bl_mode, bl_prox_max;  // bl_prox_max: proximal re-centrings of the LP after its first solve (0: none)
+    double bl_eps;                // proximal curvature of an LP (w_a = w_j = 0); excluded from the reported cost
     double state_tol;             // tolerance of the hard bounds on the measured state (constant rows of stage 0)
     double bl_aLo, bl_aHi, bl_jLo, bl_jHi;   // BL_a_LimLowVel, BL_a_LimHighVel, BL_j_LimLowVel, BL_j_LimHighVel
     // ICE-map fuel term (ab_fuel_term = 2, CreateQP_AB.m:154-159): per stage cq_k = ice_cq / tau_k, lv_k = ice_lv tau_k,

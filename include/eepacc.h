@@ -111,10 +111,12 @@ typedef struct eepacc_settings {
      * the baseline comfort limits of EstimateRouteAndComfortBounds.m:173-189 (MPCtype 1).  The caller passes
      * N_hor = BL_N_hor, Tvec[k] = BL_Ts and paramEstSetting = BL_trajEstSett (ABO/Settings.m:137-139,
      * EstimateVehicleTrajectory.m:25-29); W_AB / W_FB are ignored.  W_BL = [w_v, w_a, w_j, w_f] (ABO/Settings.m:66-71).
-     * With the reference's weights (w_a = w_j = 0) the problem is a linear program; the curvature bl_lp_eps
-     * (<= 0: 1e-4) is added to its Hessian, which leaves the solution at the LP's (least-norm) optimum
-     * (DESIGN.md section 3.7). */
-    int32_t bl_mode, bl_pad;
+     * With the reference's weights (w_a = w_j = 0) the problem is a linear program; the dual active set needs curvature,
+     * so it is solved by the proximal-point iteration  a_{j+1} = argmin LP(a) + bl_lp_eps/2 |a - a_j|^2,  a_0 = 0
+     * (bl_lp_eps <= 0: 0.1), each solve warm from the last working set, until the point stays (at most bl_prox_iter
+     * re-centrings; 0: 40, < 0: none, i.e. the single regularised solve of earlier versions): for a linear program that
+     * ends after finitely many steps at an optimum of the LP itself. */
+    int32_t bl_mode, bl_prox_iter;
     double  W_BL[4];
     double  BL_a_LimLowVel, BL_a_LimHighVel, BL_j_LimLowVel, BL_j_LimHighVel;   /* ABO/Settings.m:131-134 */
     double  bl_lp_eps;

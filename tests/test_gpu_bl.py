@@ -11,9 +11,12 @@ infeasible) are reproduced as status = 1 from the saved states when the handle's
 default (1e-9: rounding noise of the plant at standstill is let through) those steps are solved, with the forces the
 saved solution holds there.
 
-Accuracy: the kernel solves the LP with the curvature bl_lp_eps = 1e-4 on the accelerations (inverse Hessian 1e4 I);
-at nearly degenerate vertices its multiplier tolerance leaves up to 2e-6 m/s^2 (3e-3 N) on the stage-0 acceleration
-(2 of 871 saved steps), elsewhere 1e-8; the oracle's exact polish gives 1e-4 N throughout (tests/test_oracle_golden.py)."""
+How the kernel solves the LP: proximal-point iteration a_{j+1} = argmin LP(a) + bl_lp_eps/2 |a - a_j|^2 from a_0 = 0 with
+bl_lp_eps = 0.1 (inverse Hessian 10 I), every solve warm from the last working set, slides along an edge taken in one
+jump, until the point stays -- an optimum of the LP itself (include/eepacc.h).  All 870 saved steps
+with a unique optimum come out within 1e-4 N of the saved forces (qpOASES' own accuracy).  On a FACE of optima the
+limit of the iteration and the oracle's pick (least-norm optimum, curvature 1e-4) are different optimal points: there the
+tests compare the objective value, not the point (step 41; closed loops after such a step are compared loosely)."""
 import numpy as np
 import pytest
 
@@ -82,6 +85,10 @@ def test_bl_open_loop_vs_oracle(tree, torch_mod):
         assert (r["status"] != 0) == (st[i] != 0), k
         if r["status"] != 0:
             continue
+        if k in DEGENERATE:
+            # a face of optima: two different optimal points, one objective value (relative 1e-8; measured 4e-9)
+            assert abs(o[OUT["cost"], i] - r["out"][OUT["cost"]]) < 1e-8 * max(1.0, abs(r["out"][OUT["cost"]])), k
+            continue
         assert abs(o[OUT["Fm"], i] - r["out"][OUT["Fm"]]) < 1e-2 and abs(o[OUT["Fb"], i] - r["out"][OUT["Fb"]]) < 1e-2, k
         assert abs(o[OUT["a"], i] - r["out"][OUT["a"]]) < 5e-6, k
         assert abs(o[OUT["xi_f"], i] - r["out"][OUT["xi_f"]]) < 1e-6, k
@@ -91,8 +98,9 @@ def test_bl_open_loop_vs_oracle(tree, torch_mod):
 
 
 def test_bl_closed_loop_golden_and_oracle(torch_mod):
-    """Closed loop: up to the saved solution's degenerate step the trajectory equals the saved one; the whole run equals
-    the oracle's closed loop (which takes the same branch at that step); determinism; chunked = single launch."""
+    """Closed loop: up to the saved solution's degenerate step the trajectory equals the saved one and the oracle's; after it
+    (three optimal points: qpOASES' vertex, the oracle's least-norm point, the kernel's proximal limit) the bang-bang
+    trajectories stay within 0.1 m / 0.2 m/s of each other; determinism; chunked = single launch."""
     from oracle import Oracle
     OPT, V, s_tv, v_tv = make_case("ABO", 20)
     G = load_golden("abo_blmpc")
@@ -112,7 +120,8 @@ def test_bl_closed_loop_golden_and_oracle(torch_mod):
     ref, rst, _ = Oracle(BL, V).run("ab", 871, 0.0, 0.0, 0.0, s_tv[:871].copy(), v_tv[:871].copy())
     assert int((rst != 0).sum()) == 0
     for n, tol in (("s", 1e-5), ("v", 1e-5), ("a", 2e-5), ("Fm", 5e-2), ("Fb", 5e-2), ("xi_f", 1e-5)):
-        assert np.abs(tr[:, OUT[n], 0] - ref[:, OUT[n]]).max() < tol, n
+        assert np.abs(tr[:k0, OUT[n], 0] - ref[:k0, OUT[n]]).max() < tol, n
+    assert np.abs(tr[:, OUT["s"], 0] - ref[:, OUT["s"]]).max() < 0.1 and np.abs(tr[:, OUT["v"], 0] - ref[:, OUT["v"]]).max() < 0.2
     t1, s1 = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv[:300], vtv[:300])
     t2, s2 = eng.run_abmpc(np.zeros(B), np.zeros(B), np.zeros(B), stv[300:], vtv[300:], resume=True)
     assert np.array_equal(np.concatenate([t1.cpu().numpy(), t2.cpu().numpy()], 0), tr)
@@ -171,12 +180,12 @@ def test_bl_reference_use_cases(case, torch_mod):
     slopes; cut-in scenario 10): the oracle's closed loop, and every one of its states as an open-loop QP on the GPU
     (status, stage-0 acceleration, forces, slack).  Closed loops of an LP are not compared step by step: the bang-bang
     optimum is discontinuous in the state near a route feature, so a 1e-6 difference between two correct solvers
-    becomes metres (measured: 1.0 - 1.6 m on cases 2, 4, 7, 12 while every open-loop step agrees); the kernel's own
-    closed loop is checked for plausibility against the oracle's instead.
+    becomes metres, and on a face of optima the two pick different optimal points (measured: up to 12.5 m on cases 2, 4, 5
+    while every open-loop step agrees); the kernel's own closed loop is checked for plausibility against the oracle's instead.
 
-    Known limit (case 10: cut-in at 120 km/h with a 30 m gap, six stages with the slack off its bound): the kernel's
-    dual active set cycles on this degenerate LP, reports status 1 after its iteration cap and applies its last
-    iterate -- whose stage-0 acceleration equals the oracle's.  Stated here, not hidden."""
+    Case 10 (cut-in at 120 km/h with a 30 m gap, six stages with the slack off its bound) was the degenerate LP on which
+    the single regularised solve of earlier versions cycled; the proximal formulation solves it (status 0, stage-0
+    acceleration to 1e-7 of the oracle's)."""
     from oracle import Oracle
     from eepacc_mpc_casadi_matlab_amd.settings import Settings, SetVehicleParameters, default_opt
     o = default_opt(); o["useCaseNum"] = case
@@ -200,11 +209,7 @@ def test_bl_reference_use_cases(case, torch_mod):
                                 want_pred=False)
     o2 = out.cpu().numpy(); st = st.cpu().numpy()
     ok = st == 0
-    if case == 10:
-        assert (~ok).sum() <= 3 and not ok[0]          # the known limit above; measured: step 0 only
-        assert abs(o2[OUT["a_qp"], 0] - ref[0, OUT["a_qp"]]) < 1e-4
-    else:
-        assert ok.all()
+    assert ok.all()
     # accuracy: 1e-8 typical, a few 1e-6 where the slack is off its bound (multipliers of 1e7 against the curvature 1e-4)
     for n, t in dict(a_qp=3e-5, a=3e-5, xi_f=3e-5, Fm=1e-1, Fb=1e-1).items():
         assert np.abs(o2[OUT[n]][ok] - ref[ok, OUT[n]]).max() < t, (case, n)
@@ -213,8 +218,23 @@ def test_bl_reference_use_cases(case, torch_mod):
                                  s_tv[:, None].copy(), v_tv[:, None].copy())
     tr = traj.cpu().numpy()[:, :, 0]
     assert np.isfinite(tr).all()
-    assert int((status.cpu().numpy() != 0).sum()) <= (3 if case == 10 else 0)
-    assert np.abs(tr[:, OUT["s"]] - ref[:, OUT["s"]]).max() < 5.0 and np.abs(tr[:, OUT["v"]] - ref[:, OUT["v"]]).max() < 2.0, case
+    assert int((status.cpu().numpy() != 0).sum()) == 0
+    # the kernel's own closed loop, step by step: every 4th state goes to the oracle as an open-loop LP; the objective values
+    # must agree (both points optimal) whether or not the points do (faces of optima; counted, and rare)
+    orc = Oracle(BL, V)
+    vk = tr[:, OUT["v"]]
+    n_face = n_cmp = 0
+    for k in range(0, n_steps, 4):
+        inp = dict(s=float(tr[k, OUT["s"]]), v=float(vk[k]), a_prev=float(OPT["a_minus1"] if k == 0 else (vk[k] - vk[k - 1]) / Ts),
+                   t0=k * Ts, s_tv=float(s_tv[k]), v_tv=float(vm[k]), a_tv_prev=float(a_tv_prev[k]))
+        r = orc.ab_step(**inp)
+        assert r["status"] == 0, (case, k)
+        co, ck = r["out"][OUT["cost"]], tr[k, OUT["cost"]]
+        assert abs(ck - co) < 1e-7 * max(1.0, abs(co)) + 1e-5, (case, k, ck, co)
+        n_cmp += 1
+        n_face += abs(tr[k, OUT["a_qp"]] - r["out"][OUT["a_qp"]]) > 1e-4
+    assert n_face <= 0.1 * n_cmp, (case, n_face, n_cmp)
+    assert np.abs(tr[:, OUT["s"]] - ref[:, OUT["s"]]).max() < 25.0 and np.abs(tr[:, OUT["v"]] - ref[:, OUT["v"]]).max() < 5.0, case
 
 
 def test_bl_entry_points_by_name(torch_mod):
