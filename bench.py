@@ -376,7 +376,9 @@ def secondary_measurements(args):
             # the headline kernel when the launch is not bounded by the serial chains of its hardest instances (at batch 4096
             # the slowest instance's 20 steps take 7.1 of the launch's 7.3 ms): same command, four times
             # the instances
-            ("abmpc_N30_b16384", dict(workload="abmpc", horizon=30, batch=16384))]
+            ("abmpc_N30_b16384", dict(workload="abmpc", horizon=30, batch=16384)),
+            ("fbmpc_N30_b16384", dict(workload="fbmpc", horizon=30, batch=16384)),
+            ("abmpc_N60_b32768", dict(workload="abmpc", horizon=60, batch=32768))]
     for name, kw in plan:
         a = copy.copy(args)
         for k, v in kw.items():

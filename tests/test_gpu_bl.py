@@ -62,7 +62,7 @@ def test_bl_open_loop_all_golden_steps(tree, torch_mod):
         o = out.cpu().numpy(); st = status.cpu().numpy()
         assert list(np.where(st != 0)[0]) == bad
         dF = np.abs(o[OUT["Fm"]] - G["Fm_opt"]) + np.abs(o[OUT["Fb"]] - G["Fb_opt"])
-        assert dF[keep].max() < 1e-2 and (dF[keep] > 2e-4).sum() <= 3
+        assert dF[keep].max() < 2e-4          # measured: 9.7e-5 (ABO), 5.8e-5 (ORIG); qpOASES' own accuracy is 1e-4 N
         assert dF[BAD].max() < 1e-3                              # the saved iterate of the failed steps: hold still
         np.testing.assert_array_equal(o[OUT["s"]], G["s_opt"])
 
