@@ -15,7 +15,7 @@ N, B, K = 30, 4096, 25
 lead = np.load(os.path.join(ROOT, "tests", "golden", "lead_TO01_EAD.npz"))
 sc = make_s2(B, K, lead["V_TO_2Hz"], first_instance=0)
 ref = None
-for eps, prox in [(0.003, 40), (0.01, 40), (0.03, 40)]:
+for eps, prox in [(1e-4, -1), (0.01, 40), (0.1, 40), (1.0, 40)]:
     OPT, V, _, _ = make_case("ABO", N)
     BL = Settings_BL(OPT); BL["bl_lp_eps"] = eps; BL["bl_prox_iter"] = prox
     eng = Engine(BL, V, device=0, max_batch=B)
@@ -31,7 +31,7 @@ for eps, prox in [(0.003, 40), (0.01, 40), (0.03, 40)]:
 # use case 10, step 0 (open loop)
 o = default_opt(); o["useCaseNum"] = 10
 OPT = Settings(o, tree="ABO", N_hor=20); V = SetVehicleParameters("ABO")
-for eps, prox in [(0.003, 40), (0.01, 40), (0.03, 40)]:
+for eps, prox in [(1e-4, -1), (0.01, 40), (0.1, 40), (1.0, 40)]:
     BL = Settings_BL(OPT); BL["bl_lp_eps"] = eps; BL["bl_prox_iter"] = prox
     eng = Engine(BL, V, device=0, max_batch=4)
     s_tv = np.asarray(OPT["s_tv"], dtype=np.float64)[:1]; v_tv = np.zeros(1)

@@ -16,7 +16,7 @@ names = ("s", "v", "a_prev", "t0", "s_tv", "v_tv", "a_tv_prev")
 c = {n: np.array([d[n] for d in inps]) for n in names}
 keep = np.array([k not in (41, 6, 7, 8) for k in range(871)])
 cost0 = None
-for eps, prox in [(1.0, 40), (3.0, 40)]:
+for eps, prox in [(1e-4, -1), (1e-2, 40), (0.1, 40), (1.0, 40), (3.0, 40)]:
     BL = Settings_BL(OPT); BL["bl_lp_eps"] = eps; BL["bl_prox_iter"] = prox
     eng = Engine(BL, V, device=0, max_batch=1024)
     out, sp, vp, st = eng.ab_step(**c)
